@@ -1,0 +1,164 @@
+/*
+ * gpc_hip.h -- C ABI of libgpc_hip.so, the MI355X (gfx950) implementation of the
+ * openGPC sparse-stereo hot path: preprocess (3x3 box, binary Sobel, candidate
+ * mask) -> fern hash codes -> unique-code collision matching -> disparity filter.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer (header-only C++),
+ * so each entry point names the reference function it stands in for; the C++ API
+ * in include/gpc/inference.hpp forwards to these exactly where the reference's
+ * Forest methods call the raw-pointer kernels of lib/gpc/filter.hpp.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns a gpc_status (0 = ok);
+ *   - images are 8-bit, row-major, `width` a multiple of 16 (reference asserts this,
+ *     filter.hpp:294,405,549), tightly packed (stride == width);
+ *   - outputs are caller-allocated with an explicit capacity; the true count is
+ *     always returned, GPC_E_CAPACITY if it did not fit (the first `cap` entries are
+ *     valid);
+ *   - a context belongs to one device and one host thread at a time (the reference's
+ *     Forest is stateless and re-entrant; use one context per thread);
+ *   - there is NO CPU fallback: without a usable gfx950 device gpc_hip_create fails.
+ */
+#ifndef GPC_HIP_H
+#define GPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPC_HIP_ABI_VERSION 1
+#define GPC_MAX_TESTS 32   /* readForest keeps the first 32 tests, inference.hpp:426 */
+#define GPC_PATCH_RADIUS 13 /* 27x27 patch; also the candidate margin, inference.hpp:322 */
+
+typedef enum {
+  GPC_OK = 0,
+  GPC_E_INVALID = 1,      /* bad argument (null pointer, width % 16, size mismatch)      */
+  GPC_E_NO_DEVICE = 2,    /* no HIP device / not gfx950 / HIP runtime error at create    */
+  GPC_E_HIP = 3,          /* a HIP call failed; see gpc_hip_last_error                   */
+  GPC_E_CAPACITY = 4,     /* output did not fit; count returned is the true count        */
+  GPC_E_NO_FOREST = 5,    /* match/hash called before gpc_hip_set_forest                 */
+  GPC_E_FOREST_RANGE = 6, /* a test offset leaves the 27x27 patch                        */
+  GPC_E_IO = 7,           /* forest file could not be opened / parsed                    */
+  GPC_E_UNSUPPORTED = 8   /* e.g. useHashtable=true (hashmatch.hpp) -- not on this path  */
+} gpc_status;
+
+/* == ndb::Support, lib/gpc/buffer.hpp:91-97 (12 bytes) */
+typedef struct {
+  int32_t x, y;
+  float d;
+} gpc_support;
+
+/* == ndb::Correspondence, lib/gpc/buffer.hpp:99-102 (two ndb::Point) */
+typedef struct {
+  int32_t src_x, src_y, tar_x, tar_y;
+} gpc_correspondence;
+
+/* == gpc::inference::InferenceSettings, lib/gpc/inference.hpp:71-131 */
+typedef struct {
+  int32_t gradient_threshold; /* gradientThreshold_ (uint8_t), default 10 */
+  int32_t disp_high;          /* dispHigh_, default 128                    */
+  int32_t vertical_tolerance; /* verticalTolerance_, default 1             */
+  int32_t epipolar_mode;      /* epipolarMode_, default 0                  */
+  int32_t use_hashtable;      /* useHashtable_: must be 0 on this path     */
+  int32_t num_threads;        /* numThreads_: accepted, ignored            */
+} gpc_settings;
+
+/* == gpc::inference::Forest::FilterMask, lib/gpc/inference.hpp:137-156 */
+typedef struct {
+  int32_t mask[2 * GPC_MAX_TESTS]; /* mask[2t]=ix+iy*width, mask[2t+1]=jx+jy*width */
+  int32_t tau[GPC_MAX_TESTS];
+  int32_t num_tests;
+  int32_t type;      /* 0: all tau == 0 (gpcFilter), 1: gpcFilterTau */
+  int32_t width, height;
+  int32_t discarded; /* tests dropped beyond the 32nd                */
+} gpc_filter_mask;
+
+typedef struct gpc_hip_ctx gpc_hip_ctx;
+
+/* ---- library / context ------------------------------------------------------ */
+int gpc_hip_abi_version(void);
+const char* gpc_hip_status_string(int status);
+int gpc_hip_device_count(int* count);
+/* Creates a context on `device` with its own HIP stream. */
+int gpc_hip_create(int device, gpc_hip_ctx** ctx);
+int gpc_hip_destroy(gpc_hip_ctx* ctx);
+/* Last HIP error text of this context (static storage inside the context). */
+const char* gpc_hip_last_error(const gpc_hip_ctx* ctx);
+/* Borrow an externally owned hipStream_t (e.g. torch's current stream); NULL restores
+ * the context's own stream. */
+int gpc_hip_set_stream(gpc_hip_ctx* ctx, void* hip_stream);
+int gpc_hip_synchronize(gpc_hip_ctx* ctx);
+/* Pre-size device workspaces for `max_pairs` pairs of width x height (optional; the
+ * entry points below grow them on demand, which costs a hipMalloc + sync). */
+int gpc_hip_reserve(gpc_hip_ctx* ctx, int width, int height, int max_pairs);
+
+/* ---- forest ------------------------------------------------------------------ */
+/* Forest::readForest (inference.hpp:404-446): parses the text forest for an image of
+ * `width` x `height`.  Host only.  A missing file yields GPC_E_IO and an empty mask of
+ * type 0, as the reference does. */
+int gpc_hip_read_forest(const char* path, int width, int height, gpc_filter_mask* out);
+int gpc_hip_parse_forest(const char* text, int width, int height, gpc_filter_mask* out);
+/* Uploads the tests (what gpcFilter/gpcFilterTau receive as `fastmask`/`tau`,
+ * filter.hpp:547,619).  Offsets are decoded back to (dx,dy) with |d| <= 13. */
+int gpc_hip_set_forest(gpc_hip_ctx* ctx, const gpc_filter_mask* fm);
+
+/* ---- host-buffer entry points (drop-in for the Forest methods) ---------------- */
+/* Forest::preprocessImage (inference.hpp:302-333): box + clearBoundary, sobel on the
+ * raw image, ascending candidate indices with the 13-pixel margin.
+ * smooth, grad: width*height bytes; mask: capacity mask_cap ints. */
+int gpc_hip_preprocess(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height,
+                       int gradient_threshold, uint8_t* smooth, uint8_t* grad,
+                       int32_t* mask, int mask_cap, int* n_mask);
+/* ndb::gpcFilter / gpcFilterTau as called by evalFastMaskOnSubsetSSE
+ * (inference.hpp:266-292): dense code image, width*height uint32, zero where the
+ * reference leaves its zero-filled buffer untouched. */
+int gpc_hip_hash_codes(gpc_hip_ctx* ctx, const uint8_t* smooth, const uint8_t* grad,
+                       int width, int height, uint32_t* codes);
+/* Forest::rectifiedMatch (inference.hpp:375-393) on already preprocessed images.
+ * maskL/maskR are the candidate index lists of the PreprocessedImage. */
+int gpc_hip_rectified_match(gpc_hip_ctx* ctx, const uint8_t* smoothL, const uint8_t* gradL,
+                            const int32_t* maskL, int n_maskL, const uint8_t* smoothR,
+                            const uint8_t* gradR, const int32_t* maskR, int n_maskR,
+                            int width, int height, const gpc_settings* settings,
+                            gpc_support* out, int cap, int* n_out);
+/* Forest::stereoMatch (inference.hpp:344-361): correspondences, no disparity filter. */
+int gpc_hip_stereo_match(gpc_hip_ctx* ctx, const uint8_t* smoothL, const uint8_t* gradL,
+                         const int32_t* maskL, int n_maskL, const uint8_t* smoothR,
+                         const uint8_t* gradR, const int32_t* maskR, int n_maskR,
+                         int width, int height, const gpc_settings* settings,
+                         gpc_correspondence* out, int cap, int* n_out);
+/* The whole timed region of samples/sparsematch.cpp:45-52 for one pair:
+ * preprocessImage x2 + rectifiedMatch, raw host images in, supports out. */
+int gpc_hip_match_pair(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
+                       int width, int height, const gpc_settings* settings,
+                       gpc_support* out, int cap, int* n_out, int* n_cand_l, int* n_cand_r);
+
+/* ---- device-resident batch entry points ------------------------------------- */
+/* `npairs` raw pairs already in HBM ([npairs][height][width] each side) -> supports in
+ * HBM: d_out[npairs][cap_per_pair], d_counts[npairs] (true counts), and, if non-NULL,
+ * d_ncand[npairs][2] candidate counts.  Asynchronous on the context's stream. */
+int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const uint8_t* d_rawR,
+                               int width, int height, int npairs, const gpc_settings* settings,
+                               gpc_support* d_out, int cap_per_pair, int32_t* d_counts,
+                               int32_t* d_ncand);
+/* Same from/to host memory (pinned or pageable), synchronous. */
+int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
+                        int width, int height, int npairs, const gpc_settings* settings,
+                        gpc_support* out, int cap_per_pair, int32_t* counts, int32_t* ncand);
+
+/* ---- measurement -------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the context's stream.  When enabled every launch of
+ * the named kernels is bracketed by hipEvents; gpc_hip_kernel_time returns the summed
+ * milliseconds and launch count since the last reset (synchronises the stream). */
+int gpc_hip_enable_kernel_timing(gpc_hip_ctx* ctx, int enable);
+int gpc_hip_reset_kernel_timing(gpc_hip_ctx* ctx);
+int gpc_hip_kernel_count(void);
+const char* gpc_hip_kernel_name(int index);
+int gpc_hip_kernel_time(gpc_hip_ctx* ctx, int index, float* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPC_HIP_H */

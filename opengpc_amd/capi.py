@@ -1,0 +1,278 @@
+"""ctypes binding of the C ABI in include/gpc_hip.h (libgpc_hip.so).
+
+Plumbing only: numpy for host buffers, raw integer device pointers for HBM-resident
+batches (typically torch tensors' data_ptr()).  There is no CPU fallback -- if the
+shared library is missing or no gfx950 device is usable, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpc_hip.so")
+
+MAX_TESTS = 32
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_NO_FOREST, E_FOREST_RANGE, E_IO, E_UNSUPPORTED = range(9)
+
+SUPPORT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("d", "<f4")])
+CORR_DTYPE = np.dtype([("src_x", "<i4"), ("src_y", "<i4"), ("tar_x", "<i4"), ("tar_y", "<i4")])
+
+
+class Settings(C.Structure):
+    """gpc::inference::InferenceSettings (reference inference.hpp:71-131), same defaults."""
+    _fields_ = [
+        ("gradient_threshold", C.c_int32),
+        ("disp_high", C.c_int32),
+        ("vertical_tolerance", C.c_int32),
+        ("epipolar_mode", C.c_int32),
+        ("use_hashtable", C.c_int32),
+        ("num_threads", C.c_int32),
+    ]
+
+    def __init__(self, gradient_threshold=10, disp_high=128, vertical_tolerance=1,
+                 epipolar_mode=False, use_hashtable=False, num_threads=1):
+        super().__init__(int(gradient_threshold), int(disp_high), int(vertical_tolerance),
+                         int(bool(epipolar_mode)), int(bool(use_hashtable)), int(num_threads))
+
+    @classmethod
+    def sparsematch(cls):
+        """The settings of samples/sparsematch.cpp:29-34."""
+        return cls(5, 128, 0, True, False, 1)
+
+
+class FilterMask(C.Structure):
+    """gpc::inference::Forest::FilterMask (reference inference.hpp:137-156)."""
+    _fields_ = [
+        ("mask", C.c_int32 * (2 * MAX_TESTS)),
+        ("tau", C.c_int32 * MAX_TESTS),
+        ("num_tests", C.c_int32),
+        ("type", C.c_int32),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("discarded", C.c_int32),
+    ]
+
+
+class GpcError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("gpc_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+# every symbol include/gpc_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "gpc_hip_abi_version", "gpc_hip_status_string", "gpc_hip_device_count", "gpc_hip_create",
+    "gpc_hip_destroy", "gpc_hip_last_error", "gpc_hip_set_stream", "gpc_hip_synchronize",
+    "gpc_hip_reserve", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
+    "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
+    "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
+    "gpc_hip_enable_kernel_timing", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
+    "gpc_hip_kernel_name", "gpc_hip_kernel_time",
+]
+
+
+def load():
+    """Loads libgpc_hip.so (built by opengpc_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -m opengpc_amd.build` (needs hipcc). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.gpc_hip_status_string.restype = C.c_char_p
+    L.gpc_hip_last_error.restype = C.c_char_p
+    L.gpc_hip_last_error.argtypes = [C.c_void_p]
+    L.gpc_hip_kernel_name.restype = C.c_char_p
+    L.gpc_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.gpc_hip_destroy.argtypes = [C.c_void_p]
+    L.gpc_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.gpc_hip_synchronize.argtypes = [C.c_void_p]
+    L.gpc_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.gpc_hip_read_forest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FilterMask)]
+    L.gpc_hip_parse_forest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FilterMask)]
+    L.gpc_hip_set_forest.argtypes = [C.c_void_p, C.POINTER(FilterMask)]
+    L.gpc_hip_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.gpc_hip_hash_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    pre = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+           C.c_int, C.c_int, C.c_int, C.POINTER(Settings), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.gpc_hip_rectified_match.argtypes = pre
+    L.gpc_hip_stereo_match.argtypes = pre
+    L.gpc_hip_match_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.POINTER(Settings), C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gpc_hip_match_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.gpc_hip_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]
+    L.gpc_hip_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _check(L, ctx, status, allow=()):
+    if status == OK or status in allow:
+        return status
+    msg = L.gpc_hip_status_string(status).decode()
+    if status == E_HIP and ctx:
+        msg += ": " + L.gpc_hip_last_error(ctx).decode()
+    raise GpcError(status, msg)
+
+
+def read_forest(path, width, height):
+    """Forest::readForest.  Returns (status, FilterMask); a missing file gives (E_IO, empty mask)."""
+    L = load()
+    fm = FilterMask()
+    st = L.gpc_hip_read_forest(os.fsencode(path), width, height, C.byref(fm))
+    return st, fm
+
+
+def parse_forest(text, width, height):
+    L = load()
+    fm = FilterMask()
+    st = L.gpc_hip_parse_forest(text.encode(), width, height, C.byref(fm))
+    return st, fm
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One gpc_hip_ctx: one device, one stream, one host thread at a time."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        _check(self.L, None, self.L.gpc_hip_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.gpc_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, allow=()):
+        return _check(self.L, self.h, st, allow)
+
+    # ---- setup
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.gpc_hip_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._ck(self.L.gpc_hip_synchronize(self.h))
+
+    def reserve(self, width, height, max_pairs):
+        self._ck(self.L.gpc_hip_reserve(self.h, width, height, max_pairs))
+
+    def set_forest(self, fm):
+        self._ck(self.L.gpc_hip_set_forest(self.h, C.byref(fm)))
+
+    def load_forest(self, path, width, height):
+        st, fm = read_forest(path, width, height)
+        _check(self.L, None, st)
+        self.set_forest(fm)
+        return fm
+
+    # ---- host-buffer entry points
+    def preprocess(self, raw, threshold):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        H, W = raw.shape
+        smooth = np.empty((H, W), np.uint8)
+        grad = np.empty((H, W), np.uint8)
+        mask = np.empty(W * H, np.int32)
+        n = C.c_int()
+        self._ck(self.L.gpc_hip_preprocess(self.h, _ptr(raw), W, H, int(threshold), _ptr(smooth), _ptr(grad),
+                                           _ptr(mask), mask.size, C.byref(n)))
+        return smooth, grad, mask[:n.value].copy()
+
+    def hash_codes(self, smooth, grad):
+        smooth = np.ascontiguousarray(smooth, np.uint8)
+        grad = np.ascontiguousarray(grad, np.uint8)
+        H, W = smooth.shape
+        codes = np.empty((H, W), np.uint32)
+        self._ck(self.L.gpc_hip_hash_codes(self.h, _ptr(smooth), _ptr(grad), W, H, _ptr(codes)))
+        return codes
+
+    def _match_pre(self, fn, dtype, L_img, R_img, settings, cap):
+        (sl, gl, ml), (sr, gr, mr) = L_img, R_img
+        sl, gl, sr, gr = [np.ascontiguousarray(a, np.uint8) for a in (sl, gl, sr, gr)]
+        ml = np.ascontiguousarray(ml, np.int32)
+        mr = np.ascontiguousarray(mr, np.int32)
+        H, W = sl.shape
+        cap = cap if cap is not None else W * H
+        out = np.empty(max(cap, 1), dtype)
+        n = C.c_int()
+        st = fn(self.h, _ptr(sl), _ptr(gl), _ptr(ml), len(ml), _ptr(sr), _ptr(gr), _ptr(mr), len(mr), W, H,
+                C.byref(settings), _ptr(out), cap, C.byref(n))
+        self._ck(st, allow=(E_CAPACITY,))
+        return out[:min(n.value, cap)].copy(), n.value, st
+
+    def rectified_match(self, L_img, R_img, settings, cap=None):
+        """Forest::rectifiedMatch on (smooth, grad, mask) triples."""
+        return self._match_pre(self.L.gpc_hip_rectified_match, SUPPORT_DTYPE, L_img, R_img, settings, cap)
+
+    def stereo_match(self, L_img, R_img, settings, cap=None):
+        """Forest::stereoMatch on (smooth, grad, mask) triples."""
+        return self._match_pre(self.L.gpc_hip_stereo_match, CORR_DTYPE, L_img, R_img, settings, cap)
+
+    def match_pair(self, rawL, rawR, settings, cap=None):
+        rawL = np.ascontiguousarray(rawL, np.uint8)
+        rawR = np.ascontiguousarray(rawR, np.uint8)
+        H, W = rawL.shape
+        cap = cap if cap is not None else W * H
+        out = np.empty(max(cap, 1), SUPPORT_DTYPE)
+        n, nl, nr = C.c_int(), C.c_int(), C.c_int()
+        st = self.L.gpc_hip_match_pair(self.h, _ptr(rawL), _ptr(rawR), W, H, C.byref(settings), _ptr(out), cap,
+                                       C.byref(n), C.byref(nl), C.byref(nr))
+        self._ck(st, allow=(E_CAPACITY,))
+        return out[:min(n.value, cap)].copy(), n.value, (nl.value, nr.value), st
+
+    def match_batch(self, rawL, rawR, settings, cap):
+        rawL = np.ascontiguousarray(rawL, np.uint8)
+        rawR = np.ascontiguousarray(rawR, np.uint8)
+        P, H, W = rawL.shape
+        out = np.empty((P, cap), SUPPORT_DTYPE)
+        counts = np.empty(P, np.int32)
+        ncand = np.empty((P, 2), np.int32)
+        st = self.L.gpc_hip_match_batch(self.h, _ptr(rawL), _ptr(rawR), W, H, P, C.byref(settings), _ptr(out), cap,
+                                        _ptr(counts), _ptr(ncand))
+        self._ck(st, allow=(E_CAPACITY,))
+        return out, counts, ncand, st
+
+    # ---- device-resident batch (pointers are integers, e.g. torch.Tensor.data_ptr())
+    def match_batch_device(self, d_rawL, d_rawR, width, height, npairs, settings, d_out, cap_per_pair,
+                           d_counts, d_ncand=0):
+        self._ck(self.L.gpc_hip_match_batch_device(self.h, C.c_void_p(d_rawL), C.c_void_p(d_rawR), width, height,
+                                                   npairs, C.byref(settings), C.c_void_p(d_out), cap_per_pair,
+                                                   C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
+
+    # ---- measurement
+    def enable_kernel_timing(self, on=True):
+        self._ck(self.L.gpc_hip_enable_kernel_timing(self.h, int(on)))
+
+    def reset_kernel_timing(self):
+        self._ck(self.L.gpc_hip_reset_kernel_timing(self.h))
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} since the last reset."""
+        out = {}
+        for i in range(self.L.gpc_hip_kernel_count()):
+            ms, n = C.c_float(), C.c_int()
+            self._ck(self.L.gpc_hip_kernel_time(self.h, i, C.byref(ms), C.byref(n)))
+            out[self.L.gpc_hip_kernel_name(i).decode()] = (ms.value, n.value)
+        return out

@@ -1,0 +1,676 @@
+// gpc_hip.hip -- host side of libgpc_hip.so: context, workspaces, launches, C ABI.
+//
+// gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
+#include "../../include/gpc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gpc_device.h"
+#include "k_hash.h"
+#include "k_preprocess.h"
+#include "k_rowmatch.h"
+
+namespace {
+
+enum KernelId {
+  KID_PREPROCESS = 0,
+  KID_HASH,
+  KID_ROW_MATCH,
+  KID_GATHER_ROWS,
+  KID_MASK,
+  KID_GLOBAL_KEYS,
+  KID_GLOBAL_SORT,
+  KID_GLOBAL_MATCH,
+  KID_COUNT
+};
+const char* const kKernelNames[KID_COUNT] = {
+    "k_preprocess", "k_hash", "k_row_match", "k_gather_rows",
+    "k_mask", "k_global_keys", "k_global_sort", "k_global_match"};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct TimedSpan {
+  hipEvent_t a, b;
+  int kid;
+};
+
+}  // namespace
+
+struct gpc_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  char err[256] = {0};
+
+  bool have_forest = false;
+  GpcForestDev forest;
+  int forest_w = 0, forest_h = 0;
+
+  // workspaces
+  DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
+  DevBuf gkeys[2], gvals[2], ghist, gmisc;
+
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  std::vector<TimedSpan> free_spans;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call,        \
+               hipGetErrorString(e_), __FILE__, __LINE__);                             \
+      return GPC_E_HIP;                                                                \
+    }                                                                                  \
+  } while (0)
+
+#define CHK(expr)                  \
+  do {                             \
+    int s_ = (expr);               \
+    if (s_ != GPC_OK) return s_;   \
+  } while (0)
+
+int ensure(gpc_hip_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GPC_OK;
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return GPC_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+struct Timed {
+  gpc_hip_ctx* c;
+  TimedSpan s;
+  bool on;
+  Timed(gpc_hip_ctx* ctx, int kid) : c(ctx), on(ctx->timing) {
+    if (!on) return;
+    if (!c->free_spans.empty()) {
+      s = c->free_spans.back();
+      c->free_spans.pop_back();
+    } else {
+      if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) {
+        on = false;
+        return;
+      }
+    }
+    s.kid = kid;
+    (void)hipEventRecord(s.a, c->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(s.b, c->stream);
+    c->spans.push_back(s);
+  }
+};
+
+int check_dims(int W, int H) {
+  if (W <= 0 || H <= 0 || (W % 16) != 0) return GPC_E_INVALID;
+  if (W < 2 * GPC_R + 16 || H < 2 * GPC_R + 4) return GPC_E_INVALID;
+  if (W > 16384 || (long)W * H > (1l << 30)) return GPC_E_INVALID;
+  return GPC_OK;
+}
+
+int pow2_at_least(int v) {
+  int p = 2;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------- forest parsing
+
+bool next_tok(const char*& p, std::string& tok) {
+  while (*p && isspace((unsigned char)*p)) ++p;
+  if (!*p) return false;
+  const char* s = p;
+  while (*p && !isspace((unsigned char)*p)) ++p;
+  tok.assign(s, p - s);
+  return true;
+}
+
+bool next_int(const char*& p, int& v) {
+  std::string tok;
+  if (!next_tok(p, tok)) return false;
+  char* end = nullptr;
+  long l = strtol(tok.c_str(), &end, 10);
+  if (end == tok.c_str()) return false;
+  v = (int)l;
+  return true;
+}
+
+// ---------------------------------------------------------------- pipeline stages
+
+int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+                     void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
+
+// raw0/raw1 device pointers; fills smooth, grad for npairs*sides images
+int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1, int W, int H,
+                   int npairs, int sides, int thr) {
+  const int nimg = npairs * sides;
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->smooth, n * nimg));
+  CHK(ensure(c, c->grad, n * nimg));
+  CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
+  // threshold^2 passes through _mm_set1_epi16 in the reference (filter.hpp:418)
+  const int thr_sq = (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
+  dim3 grid((W / 8 + PP_TX - 1) / PP_TX, (H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS), nimg);
+  Timed t(c, KID_PREPROCESS);
+  hipLaunchKernelGGL(gpc::k_preprocess, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
+                     (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq,
+                     (int32_t*)c->stats.p);
+  HIPCHK(c, hipGetLastError());
+  return GPC_OK;
+}
+
+// smooth/grad/(candmap) device pointers for nimg images -> code image
+int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, const uint8_t* d_cand,
+             int W, int H, int nimg, bool dense, uint32_t* d_codes) {
+  if (!c->have_forest) return GPC_E_NO_FOREST;
+  dim3 grid((W + HT_X - 1) / HT_X, (H + HT_Y - 1) / HT_Y, nimg);
+  Timed t(c, KID_HASH);
+  const bool tau = c->forest.type != 0;
+  int32_t* st = (int32_t*)c->stats.p;
+#define LAUNCH_HASH(TAU, DENSE)                                                                \
+  hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE>), grid, dim3(256), 0, c->stream, d_smooth, d_grad, \
+                     d_cand, d_codes, W, H, c->forest, st)
+  if (tau && dense) LAUNCH_HASH(true, true);
+  else if (tau) LAUNCH_HASH(true, false);
+  else if (dense) LAUNCH_HASH(false, true);
+  else LAUNCH_HASH(false, false);
+#undef LAUNCH_HASH
+  HIPCHK(c, hipGetLastError());
+  return GPC_OK;
+}
+
+// code images of npairs pairs -> supports / correspondences in d_out
+int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+              void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
+  if (s->use_hashtable) return GPC_E_UNSUPPORTED;
+  const int apply_filter = (mode == 0);
+  if (s->epipolar_mode) {
+    CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)W * H * npairs));
+    CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * npairs * 2));
+    // |dy| is 0 for every epipolar match; a negative tolerance rejects everything
+    int disp_high = s->disp_high;
+    if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
+    const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
+    const size_t lds = sizeof(unsigned long long) * (size_t)nmax;
+    dim3 grid(H - 2 * GPC_R, npairs);
+    {
+      Timed t(c, KID_ROW_MATCH);
+      hipLaunchKernelGGL(gpc::k_row_match, grid, dim3(RM_THREADS), lds, c->stream,
+                         (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,
+                         (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p);
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      Timed t(c, KID_GATHER_ROWS);
+      hipLaunchKernelGGL(gpc::k_gather_rows, grid, dim3(RM_THREADS), 0, c->stream,
+                         (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
+                         cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
+      HIPCHK(c, hipGetLastError());
+    }
+    return GPC_OK;
+  }
+  return run_global_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
+}
+
+int run_global_match(gpc_hip_ctx*, int, int, int, const gpc_settings*, int, void*, int, int32_t*, int32_t*) {
+  return GPC_E_UNSUPPORTED;  // non-epipolar mode: implemented in k_global.h (next milestone)
+}
+
+int check_settings(const gpc_settings* s) {
+  if (!s) return GPC_E_INVALID;
+  if (s->gradient_threshold < 0 || s->gradient_threshold > 255) return GPC_E_INVALID;
+  if (s->use_hashtable) return GPC_E_UNSUPPORTED;
+  return GPC_OK;
+}
+
+int forest_matches(gpc_hip_ctx* c, int W, int H) {
+  if (!c->have_forest) return GPC_E_NO_FOREST;
+  // the reference asserts FilterMask dims == image dims (inference.hpp:350-353)
+  if (c->forest_w != W || c->forest_h != H) return GPC_E_INVALID;
+  return GPC_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+
+extern "C" {
+
+int gpc_hip_abi_version(void) { return GPC_HIP_ABI_VERSION; }
+
+const char* gpc_hip_status_string(int status) {
+  switch (status) {
+    case GPC_OK: return "ok";
+    case GPC_E_INVALID: return "invalid argument";
+    case GPC_E_NO_DEVICE: return "no usable HIP device (gfx950 required)";
+    case GPC_E_HIP: return "HIP runtime error";
+    case GPC_E_CAPACITY: return "output capacity too small";
+    case GPC_E_NO_FOREST: return "no forest set";
+    case GPC_E_FOREST_RANGE: return "forest test offset outside the 27x27 patch";
+    case GPC_E_IO: return "forest file could not be read";
+    case GPC_E_UNSUPPORTED: return "unsupported setting on the HIP path";
+    default: return "unknown status";
+  }
+}
+
+int gpc_hip_device_count(int* count) {
+  if (!count) return GPC_E_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return GPC_E_NO_DEVICE;
+  }
+  *count = n;
+  return GPC_OK;
+}
+
+int gpc_hip_create(int device, gpc_hip_ctx** out) {
+  if (!out) return GPC_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GPC_E_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return GPC_E_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GPC_E_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GPC_E_NO_DEVICE;
+  gpc_hip_ctx* c = new gpc_hip_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return GPC_E_NO_DEVICE;
+  }
+  c->stream = c->own_stream;
+  // the row-match kernel may need more than 64 KiB of dynamic LDS for very wide images
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_match),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  *out = c;
+  return GPC_OK;
+}
+
+int gpc_hip_destroy(gpc_hip_ctx* c) {
+  if (!c) return GPC_E_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
+                    &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
+                    &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc};
+  for (DevBuf* b : bufs) release(*b);
+  for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto& s : c->free_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return GPC_OK;
+}
+
+const char* gpc_hip_last_error(const gpc_hip_ctx* c) { return c ? c->err : "null context"; }
+
+int gpc_hip_set_stream(gpc_hip_ctx* c, void* hip_stream) {
+  if (!c) return GPC_E_INVALID;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return GPC_OK;
+}
+
+int gpc_hip_synchronize(gpc_hip_ctx* c) {
+  if (!c) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPC_OK;
+}
+
+int gpc_hip_reserve(gpc_hip_ctx* c, int W, int H, int max_pairs) {
+  if (!c || max_pairs <= 0) return GPC_E_INVALID;
+  CHK(check_dims(W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  const int nimg = 2 * max_pairs;
+  CHK(ensure(c, c->raw, n * nimg));
+  CHK(ensure(c, c->smooth, n * nimg));
+  CHK(ensure(c, c->grad, n * nimg));
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n * nimg));
+  CHK(ensure(c, c->staged, sizeof(uint32_t) * n * max_pairs));
+  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * nimg));
+  CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
+  CHK(ensure(c, c->counts, sizeof(int32_t) * nimg));
+  CHK(ensure(c, c->ncand, sizeof(int32_t) * nimg));
+  return GPC_OK;
+}
+
+// ------------------------------------------------------------------ forest
+
+int gpc_hip_parse_forest(const char* text, int W, int H, gpc_filter_mask* fm) {
+  if (!text || !fm) return GPC_E_INVALID;
+  memset(fm, 0, sizeof(*fm));
+  fm->width = W;
+  fm->height = H;
+  const char* p = text;
+  int num_ferns = 0, nonzero = 0;
+  if (!next_int(p, num_ferns)) return GPC_E_IO;
+  for (int i = 0; i < num_ferns; ++i) {
+    int fern_id, num_tests;
+    std::string scale;
+    if (!next_int(p, fern_id) || !next_tok(p, scale) || !next_int(p, num_tests)) return GPC_E_IO;
+    for (int j = 0; j < num_tests; ++j) {
+      int level, ix, iy, jx, jy, tau;
+      if (!next_int(p, level) || !next_int(p, ix) || !next_int(p, iy) || !next_int(p, jx) ||
+          !next_int(p, jy) || !next_int(p, tau))
+        return GPC_E_IO;
+      if (fm->num_tests < GPC_MAX_TESTS) {  // inference.hpp:426
+        const int t = fm->num_tests++;
+        fm->mask[2 * t] = ix + iy * W;
+        fm->mask[2 * t + 1] = jx + jy * W;
+        fm->tau[t] = tau;
+      } else {
+        fm->discarded++;
+      }
+      if (tau != 0) nonzero++;  // discarded tests count too (inference.hpp:433)
+    }
+  }
+  fm->type = nonzero ? 1 : 0;
+  return GPC_OK;
+}
+
+int gpc_hip_read_forest(const char* path, int W, int H, gpc_filter_mask* fm) {
+  if (!path || !fm) return GPC_E_INVALID;
+  memset(fm, 0, sizeof(*fm));
+  fm->width = W;
+  fm->height = H;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return GPC_E_IO;
+  std::string text;
+  char buf[4096];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, got);
+  fclose(fp);
+  return gpc_hip_parse_forest(text.c_str(), W, H, fm);
+}
+
+int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
+  if (!c || !fm) return GPC_E_INVALID;
+  if (fm->num_tests < 0 || fm->num_tests > GPC_MAX_TESTS) return GPC_E_INVALID;
+  CHK(check_dims(fm->width, fm->height));
+  const int W = fm->width;
+  GpcForestDev f;
+  memset(&f, 0, sizeof f);
+  for (int t = 0; t < fm->num_tests; ++t) {
+    int d[4];
+    for (int q = 0; q < 2; ++q) {
+      // off = dx + dy*W with |dx| <= 13 < W/2: recover (dx, dy)
+      const int off = fm->mask[2 * t + q];
+      int dy = (off >= 0) ? (off + W / 2) / W : -((-off + W / 2) / W);
+      int dx = off - dy * W;
+      if (dx < -GPC_R || dx > GPC_R || dy < -GPC_R || dy > GPC_R) return GPC_E_FOREST_RANGE;
+      d[2 * q] = dx;
+      d[2 * q + 1] = dy;
+    }
+    f.off_a[t] = (int16_t)(d[1] * HT_STRIDE + d[0]);
+    f.off_b[t] = (int16_t)(d[3] * HT_STRIDE + d[2]);
+    f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
+  }
+  f.num_tests = fm->num_tests;
+  f.type = fm->type ? 1 : 0;
+  c->forest = f;
+  c->forest_w = fm->width;
+  c->forest_h = fm->height;
+  c->have_forest = true;
+  return GPC_OK;
+}
+
+// ------------------------------------------------------------------ host-buffer entry points
+
+int gpc_hip_preprocess(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr, uint8_t* smooth,
+                       uint8_t* grad, int32_t* mask, int mask_cap, int* n_mask) {
+  if (!c || !raw) return GPC_E_INVALID;
+  if (thr < 0 || thr > 255) return GPC_E_INVALID;
+  CHK(check_dims(W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->raw, n));
+  HIPCHK(c, hipMemcpyAsync(c->raw.p, raw, n, hipMemcpyHostToDevice, c->stream));
+  CHK(run_preprocess(c, (const uint8_t*)c->raw.p, nullptr, W, H, 1, 1, thr));
+  if (smooth) HIPCHK(c, hipMemcpyAsync(smooth, c->smooth.p, n, hipMemcpyDeviceToHost, c->stream));
+  if (grad) HIPCHK(c, hipMemcpyAsync(grad, c->grad.p, n, hipMemcpyDeviceToHost, c->stream));
+  int status = GPC_OK;
+  if (n_mask || mask) {
+    const int cap = mask ? mask_cap : 0;
+    CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
+    CHK(ensure(c, c->mask, sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)));
+    CHK(ensure(c, c->counts, sizeof(int32_t) * 2));
+    dim3 grid(H - 2 * GPC_R, 1);
+    {
+      Timed t(c, KID_MASK);
+      hipLaunchKernelGGL(gpc::k_mask_count, grid, dim3(RM_THREADS), 0, c->stream, (const uint8_t*)c->grad.p,
+                         W, H, (int32_t*)c->rowcnt.p);
+      hipLaunchKernelGGL(gpc::k_mask_write, grid, dim3(RM_THREADS), 0, c->stream, (const uint8_t*)c->grad.p,
+                         W, H, (const int32_t*)c->rowcnt.p, (int32_t*)c->mask.p, cap, (int32_t*)c->counts.p);
+      HIPCHK(c, hipGetLastError());
+    }
+    int32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->counts.p, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_mask) *n_mask = cnt;
+    const int ncopy = cnt < cap ? cnt : cap;
+    if (mask && ncopy > 0)
+      HIPCHK(c, hipMemcpyAsync(mask, c->mask.p, sizeof(int32_t) * (size_t)ncopy, hipMemcpyDeviceToHost, c->stream));
+    if (mask && cnt > cap) status = GPC_E_CAPACITY;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return status;
+}
+
+int gpc_hip_hash_codes(gpc_hip_ctx* c, const uint8_t* smooth, const uint8_t* grad, int W, int H,
+                       uint32_t* codes) {
+  if (!c || !smooth || !grad || !codes) return GPC_E_INVALID;
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->smooth, n));
+  CHK(ensure(c, c->grad, n));
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n));
+  CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE));
+  HIPCHK(c, hipMemcpyAsync(c->smooth.p, smooth, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->grad.p, grad, n, hipMemcpyHostToDevice, c->stream));
+  CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 1, true,
+               (uint32_t*)c->codes.p));
+  HIPCHK(c, hipMemcpyAsync(codes, c->codes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPC_OK;
+}
+
+static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
+                              const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
+                              const int32_t* maskR, int nR, int W, int H, const gpc_settings* s, int mode,
+                              void* out, int cap, int* n_out) {
+  if (!c || !smoothL || !gradL || !smoothR || !gradR || !n_out || cap < 0 || (cap > 0 && !out)) return GPC_E_INVALID;
+  if ((nL > 0 && !maskL) || (nR > 0 && !maskR) || nL < 0 || nR < 0) return GPC_E_INVALID;
+  CHK(check_settings(s));
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  CHK(ensure(c, c->smooth, 2 * n));
+  CHK(ensure(c, c->grad, 2 * n));
+  CHK(ensure(c, c->candmap, 2 * n));
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * 2 * n));
+  CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * 2));
+  CHK(ensure(c, c->mask, sizeof(int32_t) * (size_t)((nL > nR ? nL : nR) + 1)));
+  CHK(ensure(c, c->out, esz * (size_t)(cap > 0 ? cap : 1)));
+  CHK(ensure(c, c->counts, sizeof(int32_t) * 2));
+  uint8_t* d_sm = (uint8_t*)c->smooth.p;
+  uint8_t* d_gr = (uint8_t*)c->grad.p;
+  uint8_t* d_cm = (uint8_t*)c->candmap.p;
+  HIPCHK(c, hipMemcpyAsync(d_sm, smoothL, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_sm + n, smoothR, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_gr, gradL, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_gr + n, gradR, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(d_cm, 0, 2 * n, c->stream));
+  const int32_t init_stats[2 * GPC_STAT_STRIDE] = {0, -1, 0, 0, 0, -1, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(c->stats.p, init_stats, sizeof init_stats, hipMemcpyHostToDevice, c->stream));
+  const int32_t* masks[2] = {maskL, maskR};
+  const int counts[2] = {nL, nR};
+  for (int side = 0; side < 2; ++side) {
+    if (counts[side] == 0) continue;
+    HIPCHK(c, hipMemcpyAsync(c->mask.p, masks[side], sizeof(int32_t) * (size_t)counts[side],
+                             hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(gpc::k_scatter_mask, dim3((counts[side] + 255) / 256), dim3(256), 0, c->stream,
+                       (const int32_t*)c->mask.p, counts[side], d_cm + side * n, W, H);
+    HIPCHK(c, hipGetLastError());
+    // the staging buffer is reused for the other side
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  CHK(run_hash(c, d_sm, d_gr, d_cm, W, H, 2, false, (uint32_t*)c->codes.p));
+  CHK(run_match(c, W, H, 1, s, mode, c->out.p, cap, (int32_t*)c->counts.p, nullptr));
+  int32_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(&cnt, c->counts.p, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = cnt;
+  const int ncopy = cnt < cap ? cnt : cap;
+  if (ncopy > 0) HIPCHK(c, hipMemcpy(out, c->out.p, esz * (size_t)ncopy, hipMemcpyDeviceToHost));
+  return cnt > cap ? GPC_E_CAPACITY : GPC_OK;
+}
+
+int gpc_hip_rectified_match(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
+                            const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
+                            const int32_t* maskR, int nR, int W, int H, const gpc_settings* s,
+                            gpc_support* out, int cap, int* n_out) {
+  return match_preprocessed(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, 0, out, cap, n_out);
+}
+
+int gpc_hip_stereo_match(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
+                         const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
+                         const int32_t* maskR, int nR, int W, int H, const gpc_settings* s,
+                         gpc_correspondence* out, int cap, int* n_out) {
+  return match_preprocessed(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, 1, out, cap, n_out);
+}
+
+// ------------------------------------------------------------------ batch entry points
+
+int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint8_t* d_rawR, int W, int H,
+                               int npairs, const gpc_settings* s, gpc_support* d_out, int cap_per_pair,
+                               int32_t* d_counts, int32_t* d_ncand) {
+  if (!c || !d_rawL || !d_rawR || !d_out || !d_counts || npairs <= 0 || cap_per_pair <= 0) return GPC_E_INVALID;
+  CHK(check_settings(s));
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
+  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
+               (uint32_t*)c->codes.p));
+  CHK(run_match(c, W, H, npairs, s, 0, d_out, cap_per_pair, d_counts, d_ncand));
+  return GPC_OK;
+}
+
+int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                        const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
+  if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
+  CHK(check_dims(W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->raw, 2 * n * npairs));
+  CHK(ensure(c, c->out, sizeof(gpc_support) * (size_t)cap * npairs));
+  CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
+  CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
+  uint8_t* d_l = (uint8_t*)c->raw.p;
+  uint8_t* d_r = d_l + n * npairs;
+  HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
+  CHK(gpc_hip_match_batch_device(c, d_l, d_r, W, H, npairs, s, (gpc_support*)c->out.p, cap,
+                                 (int32_t*)c->counts.p, (int32_t*)c->ncand.p));
+  HIPCHK(c, hipMemcpyAsync(counts, c->counts.p, sizeof(int32_t) * npairs, hipMemcpyDeviceToHost, c->stream));
+  if (ncand)
+    HIPCHK(c, hipMemcpyAsync(ncand, c->ncand.p, sizeof(int32_t) * 2 * npairs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int status = GPC_OK;
+  for (int p = 0; p < npairs; ++p) {
+    const int ncopy = counts[p] < cap ? counts[p] : cap;
+    if (counts[p] > cap) status = GPC_E_CAPACITY;
+    if (ncopy > 0)
+      HIPCHK(c, hipMemcpyAsync(out + (size_t)p * cap, (gpc_support*)c->out.p + (size_t)p * cap,
+                               sizeof(gpc_support) * (size_t)ncopy, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return status;
+}
+
+int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H,
+                       const gpc_settings* s, gpc_support* out, int cap, int* n_out, int* n_cand_l,
+                       int* n_cand_r) {
+  if (!n_out) return GPC_E_INVALID;
+  int32_t cnt = 0, nc[2] = {0, 0};
+  const int st = gpc_hip_match_batch(c, rawL, rawR, W, H, 1, s, out, cap, &cnt, nc);
+  *n_out = cnt;
+  if (n_cand_l) *n_cand_l = nc[0];
+  if (n_cand_r) *n_cand_r = nc[1];
+  return st;
+}
+
+// ------------------------------------------------------------------ measurement
+
+int gpc_hip_enable_kernel_timing(gpc_hip_ctx* c, int enable) {
+  if (!c) return GPC_E_INVALID;
+  c->timing = enable != 0;
+  return GPC_OK;
+}
+
+int gpc_hip_reset_kernel_timing(gpc_hip_ctx* c) {
+  if (!c) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& s : c->spans) c->free_spans.push_back(s);
+  c->spans.clear();
+  return GPC_OK;
+}
+
+int gpc_hip_kernel_count(void) { return KID_COUNT; }
+
+const char* gpc_hip_kernel_name(int index) {
+  return (index >= 0 && index < KID_COUNT) ? kKernelNames[index] : "";
+}
+
+int gpc_hip_kernel_time(gpc_hip_ctx* c, int index, float* total_ms, int* launches) {
+  if (!c || index < 0 || index >= KID_COUNT) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float tot = 0.f;
+  int cnt = 0;
+  for (auto& s : c->spans) {
+    if (s.kid != index) continue;
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, s.a, s.b));
+    tot += ms;
+    ++cnt;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
+  return GPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// k_preprocess.h -- raw image -> smooth (3x3 box + clearBoundary) and grad (binary Sobel).
+//
+// Replaces ndb::box (filter.hpp:293-392), Buffer::clearBoundary (buffer.hpp:630-654) and
+// ndb::sobel (filter.hpp:404-519) as called by Forest::preprocessImage (inference.hpp:306-313).
+//
+// HBM-bound streaming kernel: 1 byte read, 2 bytes written per pixel.  One thread owns an
+// 8-pixel-wide column strip (one aligned 8-byte load per row, 8-byte stores) and marches
+// down PP_ROWS rows with a rolling 3-row window in registers, so every raw row is read
+// (PP_ROWS+2)/PP_ROWS times.  The 8-pixel strip is also the natural unit of the
+// reference's Sobel lane-duplication quirk (4 decisions shown twice per 8 pixels).
+#pragma once
+#include "gpc_device.h"
+
+#define PP_ROWS 8      // rows per thread
+#define PP_TX 64       // threads along x per block (64 strips = 512 pixels)
+#define PP_TY 4        // row strips per block
+
+namespace gpc {
+
+__device__ __forceinline__ int third(int s) { return (s * 21846) >> 16; }  // mulhi_epi16(s,21846)
+__device__ __forceinline__ int ninth(int s) { return (s * 7282) >> 16; }   // mulhi_epi16(s,7282)
+
+struct PreRow {
+  int h[8];  // third(p[x-1]+p[x]+p[x+1]) for the 8 strip pixels
+  int a[6];  // raw pixels x0-1 .. x0+4 (the 4 Sobel decisions of the strip need these)
+};
+
+// Linear addressing as in the reference: the byte left of column 0 is the previous row's
+// last byte, the byte right of column W-1 the next row's first (filter.hpp:325-327).
+__device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, long n, int W, int H,
+                                             int r, int x0, PreRow& o) {
+  int p[10];
+  if (r < 0 || r >= H) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) p[i] = 0;
+  } else {
+    long k = (long)r * W + x0;
+    uint2 v = *reinterpret_cast<const uint2*>(raw + k);
+    p[0] = (k - 1 >= 0) ? raw[k - 1] : 0;
+    p[9] = (k + 8 < n) ? raw[k + 8] : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p[1 + i] = (v.x >> (8 * i)) & 0xFF;
+      p[5 + i] = (v.y >> (8 * i)) & 0xFF;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.h[i] = third(p[i] + p[i + 1] + p[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o.a[i] = p[i];
+}
+
+// raw0/raw1: [npairs][H][W] for side 0 / 1 (raw1 unused when sides == 1)
+// smooth/grad: [npairs*sides][H][W]
+__global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
+    const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
+    uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
+  const int img = blockIdx.z;
+  const int pair = img / sides, side = img - pair * sides;
+  const long n = (long)W * H;
+  const uint8_t* raw = (side ? raw1 : raw0) + (long)pair * n;
+  uint8_t* sm = smooth + (long)img * n;
+  uint8_t* gr = grad + (long)img * n;
+
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    img_stats[img * GPC_STAT_STRIDE + GPC_STAT_NCAND] = 0;
+    img_stats[img * GPC_STAT_STRIDE + GPC_STAT_LASTROW] = -1;
+  }
+
+  const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;
+  const int x0 = (blockIdx.x * PP_TX + tx) * 8;
+  const int ys = (blockIdx.y * PP_TY + ty) * PP_ROWS;
+  if (x0 >= W || ys >= H) return;
+
+  // last row the box filter writes: rows come in pairs from y=1 while y < H-3 (filter.hpp:307)
+  const int box_last = (H & 1) ? H - 3 : H - 4;
+
+  PreRow rows[3];
+  pre_load_row(raw, n, W, H, ys - 1, x0, rows[0]);
+  pre_load_row(raw, n, W, H, ys, x0, rows[1]);
+#pragma unroll
+  for (int i = 0; i < PP_ROWS; ++i) {
+    const int y = ys + i;
+    if (y >= H) break;
+    PreRow& up = rows[i % 3];
+    PreRow& mid = rows[(i + 1) % 3];
+    PreRow& dn = rows[(i + 2) % 3];
+    pre_load_row(raw, n, W, H, y + 1, x0, dn);
+
+    // ---- box + clearBoundary
+    uint32_t s_lo = 0, s_hi = 0;
+    if (y >= 1 && y <= box_last) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int v = third(up.h[j] + mid.h[j] + dn.h[j]);
+        const int x = x0 + j;
+        if (x < 2 || x == W - 1) v = 0;  // columns 0,1 and W-1 (buffer.hpp:637-652)
+        if (j < 4) s_lo |= (uint32_t)v << (8 * j);
+        else s_hi |= (uint32_t)v << (8 * (j - 4));
+      }
+    }
+    *reinterpret_cast<uint2*>(sm + (long)y * W + x0) = make_uint2(s_lo, s_hi);
+
+    // ---- sobel: decisions at x0..x0+3, each shown twice (filter.hpp:504-507)
+    uint32_t g_lo = 0, g_hi = 0;
+    if (y >= 1 && y <= H - 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int l0 = up.a[j], c0 = up.a[j + 1], r0 = up.a[j + 2];
+        const int l1 = mid.a[j], r1 = mid.a[j + 2];
+        const int l2 = dn.a[j], c2 = dn.a[j + 1], r2 = dn.a[j + 2];
+        const int gx = ninth(l0 + l2 + 2 * l1) - ninth(r0 + r2 + 2 * r1);
+        const int gy = ninth(l0 + r0 + 2 * c0) - ninth(l2 + r2 + 2 * c2);
+        const uint32_t e = (gx * gx + gy * gy > thr_sq) ? 0xFFFFu : 0u;
+        if (j < 2) g_lo |= e << (16 * j);
+        else g_hi |= e << (16 * (j - 2));
+      }
+    }
+    *reinterpret_cast<uint2*>(gr + (long)y * W + x0) = make_uint2(g_lo, g_hi);
+  }
+}
+
+}  // namespace gpc
