@@ -199,6 +199,7 @@ class Ref:
         self.lib = L = C.CDLL(REF_SO)
         L.gpc_ref_arr2ind.restype = C.c_int
         L.gpc_ref_is_sse.restype = C.c_int
+        L.gpc_ref_cpu_baseline_pair.restype = C.c_int
 
     @staticmethod
     def available():
@@ -245,3 +246,19 @@ class Ref:
         self.lib.gpc_ref_hash(_u8p(s), _u8p(g), _u32p(codes), _i32p(offs), _i32p(tau),
                               forest.num_tests, forest.type, W, H, nthreads)
         return codes
+
+    def cpu_baseline_pair(self, rawL, rawR, forest, settings):
+        """Reference SSE kernels + C++ port of the inference.hpp glue (std::sort); see
+        ref_harness.cpp.  Returns (supports as int32 [n][3], ms_preprocess, ms_match)."""
+        rawL = np.ascontiguousarray(rawL)
+        rawR = np.ascontiguousarray(rawR)
+        H, W = rawL.shape
+        offs = np.array(forest.offs[: 2 * forest.num_tests], np.int32)
+        tau = np.array(forest.tau[: max(forest.num_tests, 1)], np.int32)
+        out = np.empty((W * H, 3), np.int32)
+        t_pre, t_match = C.c_double(), C.c_double()
+        n = self.lib.gpc_ref_cpu_baseline_pair(
+            _u8p(rawL), _u8p(rawR), W, H, _i32p(offs), _i32p(tau), forest.num_tests, forest.type,
+            settings.gradient_threshold, settings.disp_high, settings.vertical_tolerance,
+            settings.epipolar_mode, _i32p(out), W * H, C.byref(t_pre), C.byref(t_match))
+        return out[:n].copy(), t_pre.value, t_match.value

@@ -14,7 +14,10 @@
 // API-level behaviour is pinned by SURVEY.md Appendix C instead.
 //
 // Build: see oracle/Makefile (target _ref/libgpc_ref.so).
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <iostream>
@@ -66,3 +69,130 @@ int gpc_ref_is_sse(void) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// CPU baseline for bench.py: the timed region of samples/sparsematch.cpp:45-52 with the
+// reference's REAL SSE kernels (above) and a C++ port of the inference.hpp glue around
+// them that keeps the reference's data structures and algorithms, so that its run time is
+// representative of the reference binary: 32-byte aligned zero-filled images, a zero-filled
+// uint32 code image per evaluation (inference.hpp:274), 24-byte descriptors
+// {Point, uint64 state, bool} (buffer.hpp:58-62), std::sort on them (inference.hpp:231-233),
+// the merge scan (:236-252) and the disparity filter (:384-391).  Single thread, like the
+// reference's default (inference.hpp:89).  Its output is tested against the oracle.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct Pt { int x, y; };
+struct Desc {
+  Pt point;
+  uint64_t state;
+  bool srcDescr;
+  bool operator<(const Desc& d) const { return state < d.state; }
+};
+static_assert(sizeof(Desc) == 24, "descriptor layout of buffer.hpp:58-62");
+
+struct Img {
+  uint8_t* base;
+  uint8_t* p;
+  explicit Img(size_t n) {
+    base = (uint8_t*)aligned_alloc(32, ((n + 128 + 31) / 32) * 32);
+    memset(base, 0, ((n + 128 + 31) / 32) * 32);
+    p = base + 64;  // slack in front: the SSE kernels read in[-1]
+  }
+  ~Img() { free(base); }
+  Img(const Img&) = delete;
+};
+
+struct Pre {
+  Img smooth, grad;
+  std::vector<int> mask;
+  explicit Pre(size_t n) : smooth(n), grad(n) {}
+};
+
+void preprocess(const uint8_t* raw, int W, int H, int thr, Pre& out) {
+  const size_t n = (size_t)W * H;
+  Img in(n);
+  memcpy(in.p, raw, n);
+  ndb::box(in.p, out.smooth.p, W, H, 1);
+  uint8_t* s = out.smooth.p;  // clearBoundary, buffer.hpp:630-654
+  for (int y = 0; y < H; ++y) { s[(size_t)y * W] = 0; s[(size_t)y * W + 1] = 0; s[(size_t)y * W + W - 1] = 0; }
+  memset(s, 0, W);
+  memset(s + (size_t)(H - 2) * W, 0, (size_t)2 * W);
+  ndb::sobel(in.p, out.grad.p, W, H, (uint8_t)thr, 1);
+  std::vector<int> idx(n + 64);
+  int m = 0;
+  ndb::arr2ind(out.grad.p, (int)n, idx.data(), &m);
+  out.mask.clear();
+  for (int i = 0; i < m; ++i) {  // inference.hpp:318-325
+    int x = idx[i] % W, y = idx[i] / W;
+    if (y >= 13 && y < H - 13 && x >= 13 && x < W - 13) out.mask.push_back(idx[i]);
+  }
+}
+
+std::vector<Desc> evaluate(Pre& im, const std::vector<int32_t>& mask, const std::vector<int>& tau, int type,
+                           int W, int H, bool epipolar) {
+  std::vector<uint32_t> codes((size_t)W * H, 0);
+  std::vector<int> idx;
+  if (type == 0) ndb::gpcFilter(im.smooth.p, im.grad.p, codes.data(), mask, idx, W, H, 1);
+  else ndb::gpcFilterTau(im.smooth.p, im.grad.p, codes.data(), mask, tau, idx, W, H, 1);
+  std::vector<Desc> out(im.mask.size());
+  size_t j = 0;
+  for (int k : im.mask) {
+    Desc d;
+    d.point.x = k % W;
+    d.point.y = k / W;
+    d.state = codes[k];
+    d.srcDescr = false;
+    if (epipolar) d.state |= (uint64_t)d.point.y << 32;
+    out[j++] = d;
+  }
+  return out;
+}
+
+}  // namespace
+
+extern "C" int gpc_ref_cpu_baseline_pair(const uint8_t* rawL, const uint8_t* rawR, int W, int H,
+                                         const int32_t* offs, const int32_t* tau, int ntests, int type,
+                                         int thr, int disp_high, int vtol, int epipolar,
+                                         int32_t* out_xyd /* 3 ints per support */, int cap,
+                                         double* ms_pre, double* ms_match) {
+  typedef std::chrono::high_resolution_clock clk;
+  std::vector<int32_t> mask(offs, offs + 2 * ntests);
+  std::vector<int> taus(tau, tau + ntests);
+  const size_t n = (size_t)W * H;
+  auto t0 = clk::now();
+  Pre L(n), R(n);
+  preprocess(rawL, W, H, thr, L);
+  preprocess(rawR, W, H, thr, R);
+  auto t1 = clk::now();
+  std::vector<Desc> S = evaluate(L, mask, taus, type, W, H, epipolar != 0);
+  std::vector<Desc> T = evaluate(R, mask, taus, type, W, H, epipolar != 0);
+  std::sort(S.begin(), S.end());
+  std::sort(T.begin(), T.end());
+  int count = 0;
+  if (!T.empty()) {
+    size_t j = 0;
+    const size_t last = T.size() - 1;
+    for (size_t i = 0; i < S.size(); ++i) {
+      bool unique = true;
+      while (i + 1 < S.size() && S[i].state == S[i + 1].state) { ++i; unique = false; }
+      if (!unique) continue;
+      while (j < last && T[j].state < S[i].state) ++j;
+      if (j != last && T[j].state == S[i].state && (j + 1 == last || T[j + 1].state != T[j].state)) {
+        const int dy = S[i].point.y - T[j].point.y, dx = S[i].point.x - T[j].point.x;
+        if (std::abs(dy) <= vtol && std::abs(dx) <= disp_high) {
+          if (count < cap) {
+            out_xyd[3 * count] = S[i].point.x;
+            out_xyd[3 * count + 1] = S[i].point.y;
+            out_xyd[3 * count + 2] = dx;
+          }
+          ++count;
+        }
+      }
+    }
+  }
+  auto t2 = clk::now();
+  if (ms_pre) *ms_pre = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (ms_match) *ms_match = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  return count;
+}
