@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "gpc_device.h"
+#include "k_global.h"
 #include "k_hash.h"
 #include "k_preprocess.h"
 #include "k_rowmatch.h"
@@ -240,8 +241,66 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
   return run_global_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
 }
 
-int run_global_match(gpc_hip_ctx*, int, int, int, const gpc_settings*, int, void*, int, int32_t*, int32_t*) {
-  return GPC_E_UNSUPPORTED;  // non-epipolar mode: implemented in k_global.h (next milestone)
+// Non-epipolar mode: one device-wide stable radix sort per pair (k_global.h).
+int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+                     void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
+  const size_t n = (size_t)W * H;
+  const int nmax = 2 * (W - 2 * GPC_R) * (H - 2 * GPC_R);
+  const int nblk = (nmax + GS_TILE - 1) / GS_TILE;
+  const int nmblk = (nmax + RM_THREADS - 1) / RM_THREADS;
+  for (int i = 0; i < 2; ++i) {
+    CHK(ensure(c, c->gkeys[i], sizeof(uint32_t) * (size_t)nmax));
+    CHK(ensure(c, c->gvals[i], sizeof(uint32_t) * (size_t)nmax));
+  }
+  CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * nblk + nmblk)));
+  CHK(ensure(c, c->gmisc, sizeof(int32_t) * 16));
+  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
+  int32_t* hist = (int32_t*)c->ghist.p;
+  int32_t* blkcnt = hist + (size_t)256 * nblk;
+  int32_t* gmisc = (int32_t*)c->gmisc.p;
+  int32_t* rowcnt = (int32_t*)c->rowcnt.p;
+  const int apply_filter = (mode == 0);
+  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  for (int p = 0; p < npairs; ++p) {
+    const uint32_t* codes = (const uint32_t*)c->codes.p + (size_t)p * 2 * n;
+    const int32_t* stats = (const int32_t*)c->stats.p + (size_t)p * 2 * GPC_STAT_STRIDE;
+    uint32_t* keys[2] = {(uint32_t*)c->gkeys[0].p, (uint32_t*)c->gkeys[1].p};
+    uint32_t* vals[2] = {(uint32_t*)c->gvals[0].p, (uint32_t*)c->gvals[1].p};
+    dim3 rgrid(H - 2 * GPC_R, 2);
+    {
+      Timed t(c, KID_GLOBAL_KEYS);
+      hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, rowcnt, stats, gmisc);
+      hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+                         (const int32_t*)rowcnt, stats, keys[0], vals[0], gmisc);
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      Timed t(c, KID_GLOBAL_SORT);
+      for (int pass = 0; pass < 4; ++pass) {
+        const int src = pass & 1, dst = src ^ 1;
+        hipLaunchKernelGGL(gpc::k_g_hist, dim3(nblk), dim3(GS_THREADS), 0, c->stream, (const uint32_t*)keys[src],
+                           (const int32_t*)gmisc, 8 * pass, hist, nblk);
+        hipLaunchKernelGGL(gpc::k_g_scan, dim3(1), dim3(1024), 0, c->stream, hist, 256 * nblk);
+        hipLaunchKernelGGL(gpc::k_g_scatter, dim3(nblk), dim3(GS_THREADS), 0, c->stream,
+                           (const uint32_t*)keys[src], (const uint32_t*)vals[src], keys[dst], vals[dst],
+                           (const int32_t*)gmisc, 8 * pass, (const int32_t*)hist, nblk);
+      }
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      Timed t(c, KID_GLOBAL_MATCH);
+      hipLaunchKernelGGL(gpc::k_g_match_count, dim3(nmblk), dim3(RM_THREADS), 0, c->stream,
+                         (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)gmisc, W,
+                         s->disp_high, s->vertical_tolerance, apply_filter, blkcnt);
+      hipLaunchKernelGGL(gpc::k_g_match_write, dim3(nmblk), dim3(RM_THREADS), 0, c->stream,
+                         (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)gmisc, W,
+                         s->disp_high, s->vertical_tolerance, apply_filter, (const int32_t*)blkcnt, mode,
+                         (void*)((char*)d_out + (size_t)p * cap * esz), cap, d_counts + p, stats,
+                         d_ncand ? d_ncand + 2 * p : nullptr);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  return GPC_OK;
 }
 
 int check_settings(const gpc_settings* s) {

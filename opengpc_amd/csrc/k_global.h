@@ -1,0 +1,300 @@
+// k_global.h -- non-epipolar ("global") collision matching: device-wide radix sort + scan.
+//
+// Replaces, for settings.epipolarMode_ == false, Forest::findCorrespondences
+// (std::sort x2 + merge scan, inference.hpp:227-254) and the filter of
+// Forest::rectifiedMatch (inference.hpp:384-391).
+//
+// Without the row in the state, a code must be unique over the whole left image and over
+// the whole right image.  Both descriptor sets go into ONE array of (code, side<<31 | k)
+// records -- left records first, each side in mask (row-major) order -- which a stable LSD
+// radix sort (4 passes x 8 bits over the 31-bit codes) orders by (code, side, k).  Matches
+// are then read off neighbouring records exactly as in the per-row kernel, including the
+// tail quirks of the reference's merge scan for the group of the largest right-image code.
+//
+// All sizes stay on the device (candidate counts are never read back); grids are sized for
+// the worst case N = 2*(W-26)*(H-26) and surplus workgroups exit.
+#pragma once
+#include "gpc_device.h"
+#include "k_rowmatch.h"
+
+namespace gpc {
+
+#define GS_THREADS 256
+#define GS_ITEMS 8
+#define GS_TILE (GS_THREADS * GS_ITEMS)  // records per workgroup and pass
+#define GS_WAVES (GS_THREADS / 64)
+#define GS_CHUNK (GS_TILE / GS_WAVES)    // records per wave
+
+// gmisc layout (int32): [0] number of records N, [1] largest right-image code, [2] N_L
+#define GM_N 0
+#define GM_MAXR 1
+#define GM_NL 2
+
+// ---- build the record array from the two code images of one pair --------------------
+// grid: (H - 26, 2)
+__global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __restrict__ codes, int W, int H,
+                                                           int32_t* __restrict__ rowcnt,
+                                                           const int32_t* __restrict__ stats,
+                                                           int32_t* __restrict__ gmisc) {
+  const int y = GPC_R + blockIdx.x, side = blockIdx.y;
+  const uint32_t* row = codes + ((long)side * H + y) * W;
+  int v = 0;
+  for (int x = threadIdx.x; x < W; x += RM_THREADS) v += row[x] != GPC_NOCAND;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __shared__ int s_part[RM_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < RM_THREADS / 64; ++w) s += s_part[w];
+    rowcnt[side * H + y] = s;
+    if (blockIdx.x == 0 && side == 0) {
+      const int nl = stats[GPC_STAT_NCAND], nr = stats[GPC_STAT_STRIDE + GPC_STAT_NCAND];
+      gmisc[GM_N] = nl + nr;
+      gmisc[GM_NL] = nl;
+      gmisc[GM_MAXR] = -1;
+    }
+  }
+}
+
+// grid: (H - 26, 2); runs after k_g_rowcount
+__global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restrict__ codes, int W, int H,
+                                                        const int32_t* __restrict__ rowcnt,
+                                                        const int32_t* __restrict__ stats,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        int32_t* __restrict__ gmisc) {
+  __shared__ int s_wcnt[RM_THREADS / 64];
+  const int y = GPC_R + blockIdx.x, side = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int total = block_prefix_rows(rowcnt + side * H, GPC_R, y);
+  if (side) total += stats[GPC_STAT_NCAND];  // right records follow all left records
+  const uint32_t* row = codes + ((long)side * H + y) * W;
+  int max_r = -1;
+  for (int x0 = 0; x0 < W; x0 += RM_THREADS) {
+    const int x = x0 + threadIdx.x;
+    const uint32_t c = (x < W) ? row[x] : GPC_NOCAND;
+    const bool valid = c != GPC_NOCAND;
+    const unsigned long long m = __ballot(valid);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+    if (valid) {
+      const int pos = off + __popcll(m & lanemask_lt());
+      keys[pos] = c;
+      vals[pos] = ((uint32_t)side << 31) | (uint32_t)(y * W + x);
+      if (side) max_r = max(max_r, (int)c);
+    }
+    for (int w = 0; w < RM_THREADS / 64; ++w) total += s_wcnt[w];
+    __syncthreads();
+  }
+  if (side) {
+    for (int o = 32; o > 0; o >>= 1) max_r = max(max_r, __shfl_xor(max_r, o));
+    if (lane == 0 && max_r >= 0) atomicMax(&gmisc[GM_MAXR], max_r);
+  }
+}
+
+// ---- one LSD radix pass ---------------------------------------------------------------
+// Lanes of a wave that hold the same 8-bit digit.
+__device__ __forceinline__ unsigned long long digit_peers(unsigned digit, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned long long bal = __ballot((digit >> b) & 1u);
+    peers &= ((digit >> b) & 1u) ? bal : ~bal;
+  }
+  return peers;
+}
+
+// hist[d * nblk + blk] = number of records of tile blk whose digit is d
+__global__ __launch_bounds__(GS_THREADS) void k_g_hist(const uint32_t* __restrict__ keys,
+                                                       const int32_t* __restrict__ gmisc, int shift,
+                                                       int32_t* __restrict__ hist, int nblk) {
+  __shared__ int s_hist[256];
+  const int N = gmisc[GM_N];
+  const int blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  s_hist[tid] = 0;
+  __syncthreads();
+  const int base = blk * GS_TILE + wave * GS_CHUNK;
+  if (blk * GS_TILE < N) {
+    for (int r = 0; r < GS_ITEMS; ++r) {
+      const int i = base + r * 64 + lane;
+      const bool valid = i < N;
+      const unsigned digit = valid ? ((keys[i] >> shift) & 0xFFu) : 0u;
+      const unsigned long long peers = digit_peers(digit, valid);
+      if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&s_hist[digit], __popcll(peers));
+    }
+  }
+  __syncthreads();
+  hist[tid * nblk + blk] = s_hist[tid];
+}
+
+// exclusive scan of `total` ints in place; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_g_scan(int32_t* __restrict__ data, int total) {
+  __shared__ int s_wsum[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < total; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < total) ? data[i] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+    const int carry = s_carry;
+    if (i < total) data[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ vals_in,
+                                                          uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out,
+                                                          const int32_t* __restrict__ gmisc, int shift,
+                                                          const int32_t* __restrict__ hist, int nblk) {
+  __shared__ int s_run[GS_WAVES][256];
+  const int N = gmisc[GM_N];
+  const int blk = blockIdx.x;
+  if (blk * GS_TILE >= N) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int w = 0; w < GS_WAVES; ++w) s_run[w][tid] = 0;
+  __syncthreads();
+
+  // pass A: every wave counts the digits of its own contiguous chunk (records stay in registers)
+  uint32_t k[GS_ITEMS], v[GS_ITEMS];
+  const int base = blk * GS_TILE + wave * GS_CHUNK;
+#pragma unroll
+  for (int r = 0; r < GS_ITEMS; ++r) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < N;
+    k[r] = valid ? keys_in[i] : 0u;
+    v[r] = valid ? vals_in[i] : 0u;
+    const unsigned digit = (k[r] >> shift) & 0xFFu;
+    const unsigned long long peers = digit_peers(digit, valid);
+    if (valid && (peers & lanemask_lt()) == 0) s_run[wave][digit] += __popcll(peers);
+  }
+  __syncthreads();
+  // s_run[w][d] <- global start of digit d for this tile + records of earlier waves
+  {
+    int acc = hist[tid * nblk + blk];
+    for (int w = 0; w < GS_WAVES; ++w) {
+      const int c = s_run[w][tid];
+      s_run[w][tid] = acc;
+      acc += c;
+    }
+  }
+  __syncthreads();
+  // pass B: stable ranks in (wave, round, lane) order == record order
+#pragma unroll
+  for (int r = 0; r < GS_ITEMS; ++r) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < N;
+    const unsigned digit = (k[r] >> shift) & 0xFFu;
+    const unsigned long long peers = digit_peers(digit, valid);
+    int pos = 0;
+    if (valid) pos = s_run[wave][digit] + __popcll(peers & lanemask_lt());
+    // all lanes of the wave have read s_run before the leaders update it
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      keys_out[pos] = k[r];
+      vals_out[pos] = v[r];
+      if ((peers & lanemask_lt()) == 0) s_run[wave][digit] += __popcll(peers);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- matches off the sorted records -----------------------------------------------------
+__device__ __forceinline__ bool g_match_at(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                           int i, int N, int W, uint32_t tail_code, int disp_high, int vtol,
+                                           int apply_filter, int4& m) {
+  const uint32_t code = keys[i];
+  const uint32_t v0 = vals[i];
+  if (v0 >> 31) return false;  // right record
+  const bool prev_same = (i > 0) && keys[i - 1] == code;
+  const bool n1r = (i + 1 < N) && keys[i + 1] == code && (vals[i + 1] >> 31);
+  if (prev_same || !n1r) return false;
+  const bool n2 = (i + 2 < N) && keys[i + 2] == code;
+  const bool n3 = (i + 3 < N) && keys[i + 3] == code;
+  const bool ok = (code == tail_code) ? (n2 && !n3) : !n2;
+  if (!ok) return false;
+  const int kl = (int)(v0 & 0x7FFFFFFFu), kr = (int)(vals[i + 1] & 0x7FFFFFFFu);
+  m = make_int4(kl % W, kl / W, kr % W, kr / W);
+  if (apply_filter && (abs(m.y - m.w) > vtol || abs(m.x - m.z) > disp_high)) return false;
+  return true;
+}
+
+__global__ __launch_bounds__(RM_THREADS) void k_g_match_count(const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals,
+                                                              const int32_t* __restrict__ gmisc, int W,
+                                                              int disp_high, int vtol, int apply_filter,
+                                                              int32_t* __restrict__ blkcnt) {
+  __shared__ int s_part[RM_THREADS / 64];
+  const int N = gmisc[GM_N];
+  const int i = blockIdx.x * RM_THREADS + threadIdx.x;
+  int4 m;
+  const bool hit = (i < N) && g_match_at(keys, vals, i, N, W, (uint32_t)gmisc[GM_MAXR], disp_high, vtol, apply_filter, m);
+  const unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < RM_THREADS / 64; ++w) s += s_part[w];
+    blkcnt[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(RM_THREADS) void k_g_match_write(const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals,
+                                                              const int32_t* __restrict__ gmisc, int W,
+                                                              int disp_high, int vtol, int apply_filter,
+                                                              const int32_t* __restrict__ blkcnt, int mode,
+                                                              void* __restrict__ out, int cap,
+                                                              int32_t* __restrict__ count_out,
+                                                              const int32_t* __restrict__ stats,
+                                                              int32_t* __restrict__ ncand_out) {
+  __shared__ int s_part[RM_THREADS / 64];
+  const int N = gmisc[GM_N];
+  const int off = block_prefix_rows(blkcnt, 0, blockIdx.x);
+  const int i = blockIdx.x * RM_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int4 m = make_int4(0, 0, 0, 0);
+  const bool hit = (i < N) && g_match_at(keys, vals, i, N, W, (uint32_t)gmisc[GM_MAXR], disp_high, vtol, apply_filter, m);
+  const unsigned long long b = __ballot(hit);
+  if (lane == 0) s_part[wave] = __popcll(b);
+  __syncthreads();
+  int pos = off + __popcll(b & lanemask_lt());
+  for (int w = 0; w < wave; ++w) pos += s_part[w];
+  if (hit && pos < cap) {
+    if (mode == 0) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
+      o[0] = m.x;
+      o[1] = m.y;
+      o[2] = __float_as_uint((float)(m.x - m.z));
+    } else {
+      reinterpret_cast<int4*>(out)[pos] = m;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    int total = off;
+    for (int w = 0; w < RM_THREADS / 64; ++w) total += s_part[w];
+    *count_out = total;
+    if (ncand_out) {
+      ncand_out[0] = stats[GPC_STAT_NCAND];
+      ncand_out[1] = stats[GPC_STAT_STRIDE + GPC_STAT_NCAND];
+    }
+  }
+}
+
+}  // namespace gpc
