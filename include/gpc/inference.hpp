@@ -1,0 +1,259 @@
+// inference.hpp -- gpc::inference::{InferenceSettings, Forest} on MI355X.
+//
+// Host-side mirror of the reference's lib/gpc/inference.hpp: same class, method and field
+// names, same by-value conventions, same messages on stdout, so that a caller such as
+// samples/sparsematch.cpp compiles unchanged.  Every hot method forwards to the C ABI of
+// libgpc_hip.so (include/gpc_hip.h) exactly where the reference calls its SSE kernels:
+//
+//   readForest       (inference.hpp:404-446)  -> gpc_hip_read_forest (host parser)
+//   preprocessImage  (inference.hpp:302-333)  -> gpc_hip_preprocess
+//   stereoMatch      (inference.hpp:344-361)  -> gpc_hip_stereo_match
+//   rectifiedMatch   (inference.hpp:375-393)  -> gpc_hip_rectified_match
+//   matchPair        (extension: the whole t0..t2 region of sparsematch.cpp:45-52 in one
+//                     call, raw images in, supports out -> gpc_hip_match_pair)
+//
+// There is no CPU fallback: if no gfx950 device can be opened the first hot call prints the
+// error and aborts (the reference has no error channel on these methods either).
+// One device context per host thread (thread_local), device chosen by GPC_HIP_DEVICE.
+#ifndef GPC_AMD_INFERENCE_HPP
+#define GPC_AMD_INFERENCE_HPP
+
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gpc/buffer.hpp"
+#include "gpc_hip.h"
+
+using namespace std;  // the reference's headers do this; callers rely on it (sparsematch.cpp)
+
+namespace gpc {
+namespace inference {
+
+typedef std::chrono::high_resolution_clock::time_point time_point;
+inline time_point sysTick() { return std::chrono::high_resolution_clock::now(); }
+inline float tickToMs(time_point t0, time_point t1) {
+  return (float)std::abs(1000. * std::chrono::duration_cast<std::chrono::duration<double>>(t1 - t0).count());
+}
+
+struct InferenceSettings {
+  uint8_t gradientThreshold_ = 10;
+  int dispHigh_ = 128;
+  int verticalTolerance_ = 1;
+  bool epipolarMode_ = false;
+  bool useHashtable_ = false;
+  int numThreads_ = 1;
+
+  InferenceSettings(uint8_t gradientThreshold, int dispHigh, int verticalTolerance, bool epipolarMode,
+                    bool useHashtable, int numThreads)
+      : gradientThreshold_(gradientThreshold), dispHigh_(dispHigh), verticalTolerance_(verticalTolerance),
+        epipolarMode_(epipolarMode), useHashtable_(useHashtable), numThreads_(numThreads) {}
+  InferenceSettings() {}
+  InferenceSettings& builder(void) { return *this; }
+  InferenceSettings& gradientThreshold(uint8_t v) { gradientThreshold_ = v; return *this; }
+  InferenceSettings& dispHigh(int v) { dispHigh_ = v; return *this; }
+  InferenceSettings& verticalTolerance(int v) { verticalTolerance_ = v; return *this; }
+  InferenceSettings& epipolarMode(bool v) { epipolarMode_ = v; return *this; }
+  InferenceSettings& useHashtable(bool v) { useHashtable_ = v; return *this; }
+  InferenceSettings& numThreads(int v) {  // clamped like inference.hpp:122-128; unused on the GPU
+    const int hw = (int)std::thread::hardware_concurrency();
+    numThreads_ = (v > hw) ? hw : v;
+    return *this;
+  }
+  gpc_settings toC() const {
+    gpc_settings s;
+    s.gradient_threshold = gradientThreshold_;
+    s.disp_high = dispHigh_;
+    s.vertical_tolerance = verticalTolerance_;
+    s.epipolar_mode = epipolarMode_ ? 1 : 0;
+    s.use_hashtable = useHashtable_ ? 1 : 0;
+    s.num_threads = numThreads_;
+    return s;
+  }
+};
+
+namespace detail {
+struct ContextHolder {
+  gpc_hip_ctx* ctx = nullptr;
+  // FilterMask last uploaded (the reference passes it by value into every call)
+  gpc_filter_mask uploaded;
+  bool have = false;
+  ~ContextHolder() {
+    if (ctx) gpc_hip_destroy(ctx);
+  }
+};
+inline void fail(int st, gpc_hip_ctx* ctx, const char* what) {
+  std::cout << "gpc_hip: " << what << " failed: " << gpc_hip_status_string(st);
+  if (st == GPC_E_HIP && ctx) std::cout << " (" << gpc_hip_last_error(ctx) << ")";
+  std::cout << std::endl;
+  std::abort();
+}
+inline ContextHolder& holder() {
+  static thread_local ContextHolder h;
+  if (!h.ctx) {
+    const char* dev = std::getenv("GPC_HIP_DEVICE");
+    const int st = gpc_hip_create(dev ? std::atoi(dev) : 0, &h.ctx);
+    if (st != GPC_OK) fail(st, nullptr, "gpc_hip_create");
+  }
+  return h;
+}
+}  // namespace detail
+
+class Forest {
+ public:
+  struct FilterMask {
+    std::vector<int32_t> mask;
+    std::vector<int> tau;
+    int width;
+    int height;
+    int type;
+    FilterMask(std::vector<int32_t> mask, int width, int height, int type)
+        : mask(mask), width(width), height(height), type(type) {}
+    FilterMask(std::vector<int32_t> mask, std::vector<int> tau, int width, int height, int type)
+        : mask(mask), tau(tau), width(width), height(height), type(type) {}
+  };
+  struct PreprocessedImage {
+    ndb::Buffer<uint8_t> smooth;
+    ndb::Buffer<uint8_t> grad;
+    std::vector<int> mask;
+    PreprocessedImage(ndb::Buffer<uint8_t>& smooth, ndb::Buffer<uint8_t>& grad, std::vector<int>& mask)
+        : smooth(smooth), grad(grad), mask(mask) {}
+  };
+  enum CorrMethod { sorting = 's', hashtable = 'h' };
+
+  // inference.hpp:404-446
+  FilterMask readForest(std::string path, int width, int height) {
+    gpc_filter_mask fm;
+    const int st = gpc_hip_read_forest(path.c_str(), width, height, &fm);
+    if (st == GPC_E_IO && fm.num_tests == 0 && fm.discarded == 0) {
+      cout << "Error opening forest file" << endl;
+      return FilterMask(std::vector<int32_t>(), width, height, 0);
+    }
+    // the reference prints the fern count and one note per discarded test (:417, :431)
+    cout << "number of ferns:" << countFerns(path) << endl;
+    for (int i = 0; i < fm.discarded; ++i)
+      cout << "Note: A maximum of 32 fern features are allowed, discarding remainder of forest." << endl;
+    std::vector<int32_t> mask(fm.mask, fm.mask + 2 * fm.num_tests);
+    if (fm.type == 0) return FilterMask(mask, width, height, 0);
+    std::vector<int> tau(fm.tau, fm.tau + fm.num_tests);
+    return FilterMask(mask, tau, width, height, 1);
+  }
+
+  // inference.hpp:302-333
+  PreprocessedImage preprocessImage(ndb::Buffer<uint8_t>& img, InferenceSettings settings) {
+    assert((settings.gradientThreshold_ >= 0 && settings.gradientThreshold_ <= 255) &&
+           "gradientThreshold needs to be within 0...255");
+    detail::ContextHolder& h = detail::holder();
+    ndb::Buffer<uint8_t> smooth(img.rows(), img.cols());
+    smooth.width = img.width;
+    ndb::Buffer<uint8_t> grad(img.rows(), img.cols());
+    grad.width = img.width;
+    std::vector<int> mask((size_t)img.rows() * img.cols());
+    int n = 0;
+    const int st = gpc_hip_preprocess(h.ctx, img.data(), img.cols(), img.rows(), settings.gradientThreshold_,
+                                      smooth.data(), grad.data(), mask.data(), (int)mask.size(), &n);
+    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_preprocess");
+    mask.resize(n);
+    return PreprocessedImage(smooth, grad, mask);
+  }
+
+  // inference.hpp:344-361
+  std::vector<ndb::Correspondence> stereoMatch(PreprocessedImage& simg, PreprocessedImage& timg,
+                                               FilterMask& forestmask, InferenceSettings settings) {
+    assert((forestmask.width == simg.smooth.cols() && forestmask.height == simg.smooth.rows()) &&
+           "Source Image: dimension does not fit dimension of supplied forest mask");
+    assert((forestmask.width == timg.smooth.cols() && forestmask.height == simg.smooth.rows()) &&
+           "Targe Image: dimension does not fit dimension of supplied forest mask");
+    detail::ContextHolder& h = detail::holder();
+    upload(h, forestmask);
+    const gpc_settings s = settings.toC();
+    std::vector<ndb::Correspondence> corr(std::min(simg.mask.size(), timg.mask.size()) + 1);
+    int n = 0;
+    const int st = gpc_hip_stereo_match(
+        h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
+        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
+        reinterpret_cast<gpc_correspondence*>(corr.data()), (int)corr.size(), &n);
+    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_stereo_match");
+    corr.resize(n);
+    return corr;
+  }
+
+  // inference.hpp:375-393
+  std::vector<ndb::Support> rectifiedMatch(PreprocessedImage& simg, PreprocessedImage& timg,
+                                           FilterMask& forestmask, InferenceSettings settings) {
+    assert((forestmask.width == simg.smooth.cols() && forestmask.height == simg.smooth.rows()) &&
+           "Source Image: dimension does not fit dimension of supplied forest mask");
+    detail::ContextHolder& h = detail::holder();
+    upload(h, forestmask);
+    const gpc_settings s = settings.toC();
+    std::vector<ndb::Support> supp(std::min(simg.mask.size(), timg.mask.size()) + 1);
+    int n = 0;
+    const int st = gpc_hip_rectified_match(
+        h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
+        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
+        reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n);
+    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_rectified_match");
+    supp.resize(n);
+    return supp;
+  }
+
+  // Extension: preprocessImage x2 + rectifiedMatch without bringing the intermediates back
+  // to the host (the timed region of samples/sparsematch.cpp:45-52 as one device pipeline).
+  std::vector<ndb::Support> matchPair(ndb::Buffer<uint8_t>& simg, ndb::Buffer<uint8_t>& timg, FilterMask& forestmask,
+                                      InferenceSettings settings, int* candidatesL = nullptr,
+                                      int* candidatesR = nullptr) {
+    detail::ContextHolder& h = detail::holder();
+    upload(h, forestmask);
+    const gpc_settings s = settings.toC();
+    std::vector<ndb::Support> supp((size_t)simg.rows() * simg.cols() / 2 + 1);
+    int n = 0;
+    int st = gpc_hip_match_pair(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s,
+                                reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
+                                candidatesR);
+    if (st == GPC_E_CAPACITY) {
+      supp.resize((size_t)n + 1);
+      st = gpc_hip_match_pair(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s,
+                              reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
+                              candidatesR);
+    }
+    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_match_pair");
+    supp.resize(n);
+    return supp;
+  }
+
+ private:
+  static int countFerns(const std::string& path) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    int n = 0;
+    if (fp) {
+      if (fscanf(fp, "%d", &n) != 1) n = 0;
+      fclose(fp);
+    }
+    return n;
+  }
+  static void upload(detail::ContextHolder& h, const FilterMask& f) {
+    gpc_filter_mask fm;
+    memset(&fm, 0, sizeof fm);
+    fm.num_tests = (int)(f.mask.size() / 2);
+    if (fm.num_tests > GPC_MAX_TESTS) fm.num_tests = GPC_MAX_TESTS;  // filter.hpp:574 `i < 64`
+    for (int i = 0; i < 2 * fm.num_tests; ++i) fm.mask[i] = f.mask[i];
+    for (int i = 0; i < fm.num_tests && i < (int)f.tau.size(); ++i) fm.tau[i] = f.tau[i];
+    fm.type = f.type;
+    fm.width = f.width;
+    fm.height = f.height;
+    if (h.have && memcmp(&h.uploaded, &fm, sizeof fm) == 0) return;
+    const int st = gpc_hip_set_forest(h.ctx, &fm);
+    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_set_forest");
+    h.uploaded = fm;
+    h.have = true;
+  }
+};
+
+}  // namespace inference
+}  // namespace gpc
+#endif

@@ -1,0 +1,166 @@
+"""C++ host API (include/gpc/*.hpp): host-only logic on CPU, whole path on GPU through the
+sparsematch sample -- including the reference's OWN samples/sparsematch.cpp compiled unchanged
+against these headers (when the reference tree is present)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin")
+LIBDIR = os.path.join(ROOT, "opengpc_amd")
+REF_SAMPLE = "/root/reference/samples/sparsematch.cpp"
+REF_ON_AMD = os.path.join(ROOT, "oracle", "_ref", "ref_sparsematch_on_amd_headers")
+
+
+def compile_cpp(src, out):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+                           "-L" + LIBDIR, "-lgpc_hip", "-lz", "-lpthread",
+                           "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def check_bin():
+    from opengpc_amd import build
+    build.build()
+    return compile_cpp(os.path.join(ROOT, "tests", "cpp", "host_api_check.cpp"), os.path.join(BIN, "host_api_check"))
+
+
+def run(*args, cwd=None):
+    return subprocess.run(list(args), check=True, capture_output=True, text=True, cwd=cwd).stdout
+
+
+def test_settings_and_pods(check_bin):
+    out = run(check_bin, "settings")
+    assert "DEFAULT 10 128 1 0 0 1" in out          # inference.hpp:74-89
+    assert "BUILT 5 64 0 1 0 1" in out              # numThreads clamps to hardware_concurrency
+    assert "SIZES 24 12 16" in out                  # Descriptor / Support / Correspondence layouts
+    assert "Error opening forest file" in out and "MISSING 0 0 96 64" in out
+
+
+def test_forest_reader_matches_oracle(check_bin, oracle, forest_paths):
+    for name, path in forest_paths.items():
+        out = run(check_bin, "forest", path, "1024", "436")
+        assert "number of ferns:6" in out
+        vals = out.split("FOREST")[1].split()
+        rc, f = oracle.read_forest(path, 1024, 436)
+        assert int(vals[0]) == 60 and int(vals[2]) == f.type
+        assert int(vals[1]) == (30 if f.type else 0)    # tau stays empty for a zero forest
+        assert [int(v) for v in vals[3:]] == list(f.offs[:60])
+
+
+def test_png_read(check_bin, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    cases = {
+        "gray": (rng.integers(0, 256, (37, 50), dtype=np.uint8), "L"),
+        "rgb": (rng.integers(0, 256, (20, 64, 3), dtype=np.uint8), "RGB"),
+        "rgba": (rng.integers(0, 256, (8, 16, 4), dtype=np.uint8), "RGBA"),
+    }
+    for name, (arr, mode) in cases.items():
+        p = str(tmp_path / (name + ".png"))
+        Image.fromarray(arr, mode).save(p)
+        raw = str(tmp_path / (name + ".raw"))
+        out = run(check_bin, "read", p, raw)
+        rc, cols, rows, w, h = map(int, out.split("RESULT")[1].split())
+        H, W = arr.shape[:2]
+        assert (rows, w, h, cols) == (H, W, H, (W + 15) // 16 * 16)
+        buf = np.fromfile(raw, np.uint8).reshape(rows, cols)
+        if name == "rgba":
+            assert rc == 1 and "other than gray or 3 channel" in out   # buffer.hpp:309-313
+            continue
+        assert rc == 0
+        want = arr if name == "gray" else (arr.astype(np.int32).sum(2) // 3).astype(np.uint8)
+        assert np.array_equal(buf[:, :W], want) and not buf[:, W:].any()
+    out = run(check_bin, "read", str(tmp_path / "missing.png"), str(tmp_path / "x.raw"))
+    assert "could not be opened for reading" in out and "RESULT 1" in out
+    notpng = tmp_path / "not.png"
+    notpng.write_bytes(b"hello world, not a png")
+    out = run(check_bin, "read", str(notpng), str(tmp_path / "y.raw"))
+    assert "is not recognized as a PNG file" in out and "RESULT 1" in out
+
+
+def test_png_write_and_visualisation(check_bin, tmp_path):
+    from PIL import Image
+    p = str(tmp_path / "g.png")
+    run(check_bin, "write_gray", "50", "21", p)
+    g = np.array(Image.open(p))
+    y, x = np.mgrid[0:21, 0:50]
+    assert g.shape == (21, 50) and np.array_equal(g, ((x * 3 + y * 7) & 0xFF).astype(np.uint8))
+    p = str(tmp_path / "c.png")
+    run(check_bin, "write_rgb", "33", "9", p)
+    c = np.array(Image.open(p))
+    y, x = np.mgrid[0:9, 0:33]
+    assert np.array_equal(c, np.stack([x & 0xFF, y & 0xFF, (x ^ y) & 0xFF], -1).astype(np.uint8))
+    p = str(tmp_path / "v.png")
+    run(check_bin, "vis", "64", "48", p)
+    v = np.array(Image.open(p)).astype(np.int32)
+    y, x = np.mgrid[0:48, 0:64]
+    off = x != y
+    assert np.all(v[off] == ((x + y) & 0xFF)[off][:, None])          # untouched pixels stay gray
+    assert tuple(v[0, 0]) == (0, 0, 255) and v[40, 40, 0] > v[2, 2, 0]  # ramp starts blue, reddens
+
+
+def test_clear_boundary(check_bin, tmp_path, oracle):
+    raw = str(tmp_path / "cb.raw")
+    out = run(check_bin, "clear", "48", "20", raw)
+    buf = np.fromfile(raw, np.uint8).reshape(20, 48)
+    want = np.full((20, 48), 255, np.uint8)
+    oracle.clear_boundary(want)
+    assert np.array_equal(buf, want)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SAMPLE), reason="reference tree not present")
+def test_reference_sample_compiles_unchanged_against_these_headers():
+    """Drop-in at source level: the reference's samples/sparsematch.cpp, untouched, builds
+    against include/gpc/*.hpp.  The binary goes to oracle/_ref (derived from reference source)."""
+    compile_cpp(REF_SAMPLE, REF_ON_AMD)
+    assert os.path.exists(REF_ON_AMD)
+
+
+def write_pair(tmp_path, W, H, s, D):
+    from PIL import Image
+    from opengpc_amd.synth import synth_pair
+    L, R = synth_pair(W, H, s, D)
+    lp, rp = str(tmp_path / "left.png"), str(tmp_path / "right.png")
+    Image.fromarray(L, "L").save(lp)
+    Image.fromarray(np.stack([R, R, R], -1), "RGB").save(rp)   # RGB input takes the (r+g+b)/3 path
+    return L, R, lp, rp
+
+
+LINE = re.compile(r"#candidatesL:(\d+), #candidatesR:(\d+), tMatch: [\d.e+-]+ ms, num matches:(\d+)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_sparsematch_sample(tmp_path, golden, forest_paths, fused):
+    from PIL import Image
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "samples")])
+    c = golden["cases"][1]
+    L, R, lp, rp = write_pair(tmp_path, c["W"], c["H"], c["s"], c["D"])
+    args = [os.path.join(ROOT, "samples", "sparsematch"), forest_paths["zero"], lp, rp] + (["--fused"] if fused else [])
+    out = run(*args, cwd=str(tmp_path))
+    m = LINE.search(out)
+    assert m, out
+    assert [int(m.group(1)), int(m.group(2))] == c["n_cand"]
+    assert int(m.group(3)) == c["zero"]["epipolar"]["n"]
+    vis = np.array(Image.open(str(tmp_path / "disparity.png")))
+    assert vis.shape == (c["H"], c["W"], 3)
+    changed = np.any(vis != L[:, :, None], axis=2)
+    assert 0 < changed.sum() <= c["zero"]["epipolar"]["n"]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_ON_AMD), reason="reference sample build not present")
+def test_reference_sample_runs_on_the_hip_path(tmp_path, golden, forest_paths):
+    c = golden["cases"][1]
+    L, R, lp, rp = write_pair(tmp_path, c["W"], c["H"], c["s"], c["D"])
+    out = run(REF_ON_AMD, forest_paths["tau"], lp, rp, cwd=str(tmp_path))
+    m = LINE.search(out)
+    assert m, out
+    assert [int(m.group(1)), int(m.group(2)), int(m.group(3))] == c["n_cand"] + [c["tau"]["epipolar"]["n"]]
+    assert os.path.exists(str(tmp_path / "disparity.png"))
