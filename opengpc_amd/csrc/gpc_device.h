@@ -13,16 +13,19 @@
 #define GPC_STAT_NCAND 0
 #define GPC_STAT_LASTROW 1
 
-// hash kernel tile: 64 x 16 outputs, smooth staged with a 16-byte aligned 16-pixel apron
-#define HT_X 64
+// hash kernel tile: 256 x 16 outputs (4 pixels per lane), smooth staged with a 16-byte aligned 16-pixel apron
+#define HT_X 256
 #define HT_Y 16
 #define HT_APRON 16
-#define HT_STRIDE (HT_X + 2 * HT_APRON)  // 96 bytes per LDS row
+#define HT_STRIDE (HT_X + 2 * HT_APRON)  // 288 bytes per LDS row
 #define HT_ROWS (HT_Y + 2 * GPC_R)       // 42 rows
+#define HT_COPY (HT_ROWS * HT_STRIDE)    // bytes of one (shifted) copy of the window
 
+// Passed BY VALUE as a kernel argument: every field is a 32-bit scalar the compiler keeps in
+// SGPRs (s_load from the kernarg segment), so a tap address is `lane base + SGPR`.
 struct GpcForestDev {
-  int16_t off_a[32];  // LDS byte offset of tap i:  iy * HT_STRIDE + ix
-  int16_t off_b[32];  // LDS byte offset of tap j
+  int32_t off[32];    // LDS DWORD offsets of a test's two taps, packed (off_a & 0xFFFF) | (off_b << 16);
+                      // byte offset = (dx & 3) * HT_COPY + dy * HT_STRIDE + (dx - (dx & 3))
   int32_t tau[32];    // (int8_t) tau, sign-extended
   int32_t num_tests;
   int32_t type;

@@ -488,8 +488,13 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
       d[2 * q] = dx;
       d[2 * q + 1] = dy;
     }
-    f.off_a[t] = (int16_t)(d[1] * HT_STRIDE + d[0]);
-    f.off_b[t] = (int16_t)(d[3] * HT_STRIDE + d[2]);
+    // the hash kernel keeps 4 byte-shifted copies of the window: tap (dx,dy) is an aligned dword of copy dx&3
+    int offs[2];
+    for (int q = 0; q < 2; ++q) {
+      const int dx = d[2 * q], dy = d[2 * q + 1], sft = dx & 3;
+      offs[q] = (sft * HT_COPY + dy * HT_STRIDE + (dx - sft)) / 4;
+    }
+    f.off[t] = (offs[0] & 0xFFFF) | (offs[1] << 16);
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
   }
   f.num_tests = fm->num_tests;

@@ -4,12 +4,21 @@
 // zero-filled code buffer and descriptor gather of Forest::evalFastMaskOnSubsetSSE
 // (inference.hpp:274-290).
 //
-// One 256-thread workgroup owns a 64x16 output tile.  The (64+32) x (16+26) smooth window
-// is staged once into LDS with 16-byte coalesced loads (252 chunks, one per thread); the
-// tests (LDS byte offsets, tau) arrive as a by-value kernel argument, i.e. in SGPRs, so
-// every tap is one ds_read_u8 at `lane base + scalar offset`.  A wave covers one image row
-// of 64 pixels per step: all lanes read the same LDS row -> conflict-free (4 lanes share a
-// dword, broadcast).  Per test: v_sub + v_alignbit.  No MFMA: this is gather/compare.
+// Layout of the work (gfx950):
+//   * a 256-thread workgroup owns a 256 x 16 output tile; the (256+32) x (16+26) smooth
+//     window is staged once into LDS with 16-byte coalesced loads;
+//   * a LANE owns 4 horizontally adjacent pixels, a WAVE one 256-pixel row segment per step
+//     and 4 rows in total.  The window is kept in LDS FOUR times, copy s shifted left by s
+//     bytes, so a tap for 4 pixels is ONE ALIGNED ds_read_b32 from copy (dx & 3) at
+//     `lane base + SGPR offset + row immediate` (unaligned LDS dwords work on gfx950 but
+//     measured ~20x slower).  64 lanes read 256 contiguous bytes: conflict-free, and 4x fewer
+//     LDS instructions than a byte gather -- LDS issue rate, not HBM, bounds this kernel;
+//   * the four unsigned byte compares of a test are done SWAR in 5 VALU ops and shifted into
+//     byte planes exactly like the reference's out[0..3] registers (7 ops per test and 4
+//     pixels); the planes are transposed into 4 codes with v_perm_b32 at the end;
+//   * the tests (packed LDS offsets, tau) arrive as a by-value kernel argument and live in
+//     SGPRs; the test loop is fully unrolled in branch-free groups so reads are batched.
+// No MFMA: this is gather/compare.
 //
 // Output is a dense code image (u32 per pixel): the code for candidates, GPC_NOCAND for
 // everything else (DENSE=false), or exactly the reference's gpcstates buffer (DENSE=true,
@@ -19,31 +28,44 @@
 
 namespace gpc {
 
-template <bool TAU>
-__device__ __forceinline__ uint32_t fern_code(const uint8_t* __restrict__ tile, int base,
-                                              const GpcForestDev& f, int x) {
-  // Evaluate tests last-to-first so that test t lands on bit t of `acc`.
-  uint32_t acc = 0;
-#pragma unroll 4
-  for (int t = f.num_tests - 1; t >= 0; --t) {
-    const int a = tile[base + f.off_a[t]];
-    int b = tile[base + f.off_b[t]];
-    if (TAU) {
-      // _mm_subs_epi8(b, tau): signed saturating byte subtract, result reinterpreted as
-      // unsigned for the compare (filter.hpp:647-652)
-      int sb = (int)(int8_t)b - f.tau[t];
-      sb = min(max(sb, -128), 127);
-      b = sb & 0xFF;
-    }
-    // (b - a) is negative iff a > b; shift its sign bit into acc
-    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(b - a), 31);
+#define SW_H 0x80808080u
+#define SW_M 0x7F7F7F7Fu
+
+// bit 7 of every byte: (b_byte >= a_byte), unsigned; the other bits are garbage
+__device__ __forceinline__ uint32_t swar_ge(uint32_t a, uint32_t b) {
+  const uint32_t d = (b | SW_H) - (a & SW_M);  // per byte b_lo + 128 - a_lo: no borrow crosses bytes
+  const uint32_t x = a ^ b;
+  return (x & b) | (~x & d);                   // top bits differ -> b's top bit decides (v_bfi_b32)
+}
+
+// _mm_subs_epi8(b, tau) on 4 packed bytes: signed saturating subtract (filter.hpp:649-651)
+__device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, int tau) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int v = (int)(int8_t)(b >> (8 * j)) - tau;
+    v = min(max(v, -128), 127);
+    r |= (uint32_t)(v & 0xFF) << (8 * j);
   }
-  // Bit placement of the reference's four byte planes (filter.hpp:574-595): tests 0..7 ->
-  // bits 0..7; test 8 -> bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask);
-  // tests 9..31 -> bits 8..30.
-  uint32_t code = (acc & 0xFFu) | ((acc >> 9) << 8);
-  if ((acc & 0x100u) && (x & 7)) code |= 1u;
-  return code;
+  return r;
+}
+
+// One test for RPW rows: shift the 4 compare bits of every row into its byte plane
+// (new bit enters at bit 7, so the first test of a plane ends up on bit 0 after 8 steps).
+template <bool TAU, int RPW>
+__device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int lanebase, int packed, int tau,
+                                          uint32_t (&plane)[RPW]) {
+  // packed: dword offsets (copy select + row + column) of the two taps
+  const uint32_t* pa = reinterpret_cast<const uint32_t*>(tile + lanebase) + (int)(int16_t)(packed & 0xFFFF);
+  const uint32_t* pb = reinterpret_cast<const uint32_t*>(tile + lanebase) + (packed >> 16);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    uint32_t a = pa[r * (HT_STRIDE / 4)];
+    uint32_t b = pb[r * (HT_STRIDE / 4)];
+    if (TAU) b = subs_epi8x4(b, tau);
+    const uint32_t ge = swar_ge(a, b);
+    plane[r] = (ge & SW_H) | ((plane[r] >> 1) & SW_M);
+  }
 }
 
 // smooth, grad, candmap: [nimg][H][W]; codes: [nimg][H][W] u32
@@ -54,7 +76,8 @@ __global__ __launch_bounds__(256) void k_hash(const uint8_t* __restrict__ smooth
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
                                               GpcForestDev f, int32_t* __restrict__ img_stats) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[HT_ROWS * HT_STRIDE];
+  constexpr int RPW = HT_Y / 4;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
   __shared__ int s_cnt, s_last;
 
   const int img = blockIdx.z;
@@ -70,42 +93,134 @@ __global__ __launch_bounds__(256) void k_hash(const uint8_t* __restrict__ smooth
 
   // ---- stage the smooth window; linear addressing like the reference's unaligned loads,
   //      bytes outside the buffer read as 0
+  //      copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
   for (int c = tid; c < HT_ROWS * (HT_STRIDE / 16); c += 256) {
     const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
     const long k = (long)(ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
     uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t nx = 0;
     if (k >= 0 && k + 16 <= n) v = *reinterpret_cast<const uint4*>(sm + k);
-    *reinterpret_cast<uint4*>(tile + r * HT_STRIDE + q * 16) = v;
+    if (q + 1 < HT_STRIDE / 16 && k + 16 >= 0 && k + 20 <= n) nx = *reinterpret_cast<const uint32_t*>(sm + k + 16);
+    uint8_t* dst = tile + r * HT_STRIDE + q * 16;
+    *reinterpret_cast<uint4*>(dst) = v;
+#pragma unroll
+    for (int sft = 1; sft < 4; ++sft) {
+      uint4 w;
+      w.x = __builtin_amdgcn_alignbyte(v.y, v.x, sft);
+      w.y = __builtin_amdgcn_alignbyte(v.z, v.y, sft);
+      w.z = __builtin_amdgcn_alignbyte(v.w, v.z, sft);
+      w.w = __builtin_amdgcn_alignbyte(nx, v.w, sft);
+      *reinterpret_cast<uint4*>(dst + sft * HT_COPY) = w;
+    }
   }
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int x = tx0 + lane;
-  int cnt = 0, last = -1;
-#pragma unroll 1
-  for (int rr = 0; rr < HT_Y / 4; ++rr) {
-    const int ly = wave * (HT_Y / 4) + rr;
-    const int y = ty0 + ly;
-    const bool inimg = (x < W) && (y < H);
-    const long k = (long)y * W + x;
-    const int g = inimg ? gr[k] : 0;
-    const bool margin = x >= GPC_R && x < W - GPC_R && y >= GPC_R && y < H - GPC_R;
-    const bool cand = margin && ((cm ? (int)cm[k] : g) != 0);
-    // the reference skips 16-pixel groups without any gradient byte (filter.hpp:566)
-    const unsigned long long gm = __ballot(g != 0);
-    const bool group_any = ((gm >> (lane & 48)) & 0xFFFFull) != 0;
-    const bool rows_ok = y >= GPC_R && y < H - 15;  // gpcFilterSegment(13, height-15) :602
-    const bool compute = DENSE ? (inimg && rows_ok && group_any) : (cand && rows_ok && group_any);
-    uint32_t code = 0;
-    if (compute) {
-      const int base = (ly + GPC_R) * HT_STRIDE + lane + HT_APRON;
-      code = fern_code<TAU>(tile, base, f, x);
+  const int x0 = tx0 + 4 * lane;
+  const int yw = ty0 + wave * RPW;  // first row of this wave
+
+  // ---- per row: gradient bytes, candidate flags (bit j = pixel x0+j), group-of-16 activity
+  uint32_t candbits[RPW];
+  bool rowdo[RPW];
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int y = yw + r;
+    const bool inimg = (x0 < W) && (y < H);
+    const long k = (long)y * W + x0;
+    const uint32_t g4 = inimg ? *reinterpret_cast<const uint32_t*>(gr + k) : 0u;
+    const uint32_t c4 = cm ? (inimg ? *reinterpret_cast<const uint32_t*>(cm + k) : 0u) : g4;
+    uint32_t cb = 0;
+    if (y >= GPC_R && y < H - GPC_R) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 + j;
+        if (((c4 >> (8 * j)) & 0xFFu) && x >= GPC_R && x < W - GPC_R) cb |= 1u << j;
+      }
     }
-    if (inimg) out[k] = DENSE ? code : (cand ? code : GPC_NOCAND);
-    const unsigned long long cmask = __ballot(cand);
-    if (cmask) { cnt += __popcll(cmask); last = y; }
+    // the reference skips 16-pixel groups (4 lanes here) without any gradient byte (filter.hpp:566)
+    const unsigned long long gm = __ballot(g4 != 0);
+    const bool group_any = ((gm >> (lane & 60)) & 0xFull) != 0;
+    const bool rows_ok = y >= GPC_R && y < H - 15;  // gpcFilterSegment(13, height-15) :602
+    candbits[r] = cb;
+    rowdo[r] = inimg && rows_ok && group_any;
+    any = any || (DENSE ? rowdo[r] : (cb != 0 && rowdo[r]));
+  }
+
+  // ---- the tests, in the reference's byte planes: P0 = tests 0..7, (test 8), P1 = 9..16,
+  //      P2 = 17..24, P3 = 25..31.  Tests >= T are padded with equal taps (compare false).
+  uint32_t code[RPW][4];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) code[r][j] = 0;
+
+  if (__ballot(any)) {  // wave-uniform: skip segments with nothing to hash
+    const int T = f.num_tests;
+    const int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
+    uint32_t p0[RPW], p1[RPW], p2[RPW], p3[RPW], p8[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) p0[r] = p1[r] = p2[r] = p3[r] = p8[r] = ~0u;  // "ge" planes: all-ones = no bit
+    if (T > 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
+    }
+    if (T > 8) fern_test<TAU, RPW>(tile, lanebase, f.off[8], f.tau[8], p8);
+    if (T > 9) {
+#pragma unroll
+      for (int t = 9; t < 17; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
+    }
+    if (T > 17) {
+#pragma unroll
+      for (int t = 17; t < 25; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
+    }
+    if (T > 25) {
+#pragma unroll
+      for (int t = 25; t < 32; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+    }
+    // test 8 is OR-ed into bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask)
+    const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      // planes hold "b >= a"; the code bit is its complement.  P3 saw 7 tests: one more shift.
+      const uint32_t q0 = ~p0[r] | ((~p8[r] >> 7) & m8);
+      const uint32_t q1 = ~p1[r];
+      const uint32_t q2 = ~p2[r];
+      const uint32_t q3 = (~p3[r] >> 1) & SW_M;
+      // transpose 4 planes x 4 pixels -> 4 codes (byte k of code j = plane k, byte j)
+      const uint32_t lo01 = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
+      const uint32_t hi01 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
+      const uint32_t lo23 = __builtin_amdgcn_perm(q3, q2, 0x05010400u);
+      const uint32_t hi23 = __builtin_amdgcn_perm(q3, q2, 0x07030602u);
+      code[r][0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+      code[r][1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+      code[r][2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+      code[r][3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+    }
+  }
+
+  // ---- store (16 bytes per lane and row, 1 KiB per wave and row) + statistics
+  int cnt = 0, last = -1;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int y = yw + r;
+    if ((x0 < W) && (y < H)) {
+      uint4 o;
+      uint32_t* op = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t c = rowdo[r] ? code[r][j] : 0u;
+        op[j] = DENSE ? c : (((candbits[r] >> j) & 1u) ? c : GPC_NOCAND);
+      }
+      *reinterpret_cast<uint4*>(out + (long)y * W + x0) = o;
+    }
+    if (candbits[r]) { cnt += __popc(candbits[r]); last = y; }
   }
   if (!DENSE) {
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt += __shfl_xor(cnt, o);
+      last = max(last, __shfl_xor(last, o));
+    }
     if (lane == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicMax(&s_last, last); }
     __syncthreads();
     if (tid == 0 && s_cnt) {
