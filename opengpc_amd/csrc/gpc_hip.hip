@@ -16,6 +16,7 @@
 #include "k_global.h"
 #include "k_hash.h"
 #include "k_preprocess.h"
+#include "k_rowjoin.h"
 #include "k_rowmatch.h"
 
 namespace {
@@ -60,6 +61,8 @@ struct gpc_hip_ctx {
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc;
+
+  bool force_lds_sort = false;  // GPC_HIP_ROWMATCH=lds: first-generation row kernel (A/B checks)
 
   // timing
   bool timing = false;
@@ -219,14 +222,37 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     // |dy| is 0 for every epipolar match; a negative tolerance rejects everything
     int disp_high = s->disp_high;
     if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
-    const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
-    const size_t lds = sizeof(unsigned long long) * (size_t)nmax;
     dim3 grid(H - 2 * GPC_R, npairs);
+    // second-generation kernel: LDS hash join + register bitonic sort (k_rowjoin.h); the
+    // LDS-sort kernel (k_rowmatch.h) remains for very wide images and for A/B checks.
+    int spt = 1;
+    while (spt * RJ_THREADS < W) spt <<= 1;
+    int log2s = 1;
+    while ((1 << log2s) <= 2 * (W - 2 * GPC_R)) ++log2s;
+    const size_t join_lds = (size_t)16 * (1u << log2s) + (size_t)4 * RJ_THREADS * spt;
+    const bool use_join = !c->force_lds_sort && spt <= 16 && join_lds <= 150 * 1024;
     {
       Timed t(c, KID_ROW_MATCH);
-      hipLaunchKernelGGL(gpc::k_row_match, grid, dim3(RM_THREADS), lds, c->stream,
-                         (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,
-                         (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p);
+      if (use_join) {
+#define LAUNCH_JOIN(SPT)                                                                          \
+  hipLaunchKernelGGL(gpc::k_row_join<SPT>, grid, dim3(RJ_THREADS), join_lds, c->stream,           \
+                     (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
+                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s)
+        switch (spt) {
+          case 1: LAUNCH_JOIN(1); break;
+          case 2: LAUNCH_JOIN(2); break;
+          case 4: LAUNCH_JOIN(4); break;
+          case 8: LAUNCH_JOIN(8); break;
+          default: LAUNCH_JOIN(16); break;
+        }
+#undef LAUNCH_JOIN
+      } else {
+        const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
+        const size_t lds = sizeof(unsigned long long) * (size_t)nmax;
+        hipLaunchKernelGGL(gpc::k_row_match, grid, dim3(RM_THREADS), lds, c->stream,
+                           (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,
+                           (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p);
+      }
       HIPCHK(c, hipGetLastError());
     }
     {
@@ -368,8 +394,16 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   }
   c->stream = c->own_stream;
   // the row-match kernel may need more than 64 KiB of dynamic LDS for very wide images
+  const int max_dyn = 160 * 1024 - 2048;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_match),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  const char* rm = getenv("GPC_HIP_ROWMATCH");
+  c->force_lds_sort = rm && !strcmp(rm, "lds");
   *out = c;
   return GPC_OK;
 }
