@@ -29,7 +29,8 @@ namespace gpc {
 // ---------------------------------------------------------------- lane exchanges
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  // every lane has a valid source for the controls used here, so `old` is never selected
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // value of `v` held by lane (lane ^ LM); LM in {1,2,3,4,7,8,15,16,31,32,63}
@@ -76,7 +77,11 @@ __device__ __forceinline__ void sort_stage(uint32_t (&key)[SPT], uint32_t* __res
     for (int r = 0; r < SPT; ++r) p[r] = lane_xor<MLANE>(key[r ^ MREG]);
     const bool lower = ((tid & 63) & highest_bit(MLANE)) == 0;
 #pragma unroll
-    for (int r = 0; r < SPT; ++r) key[r] = lower ? min(key[r], p[r]) : max(key[r], p[r]);
+    for (int r = 0; r < SPT; ++r) {
+      // lower index keeps the smaller key: one compare, the mask XOR is scalar, one select
+      const bool take = (p[r] < key[r]) == lower;
+      key[r] = take ? p[r] : key[r];
+    }
   } else {
     const int base = tid * SPT;
 #pragma unroll
@@ -86,7 +91,8 @@ __device__ __forceinline__ void sort_stage(uint32_t (&key)[SPT], uint32_t* __res
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const uint32_t p = xbuf[(base + r) ^ M];
-      key[r] = lower ? min(key[r], p) : max(key[r], p);
+      const bool take = (p < key[r]) == lower;
+      key[r] = take ? p : key[r];
     }
     __syncthreads();
   }
@@ -148,13 +154,18 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
   // ---- 1. insert both rows
   const uint32_t* rowl = codes + ((long)(pair * 2) * H + y) * W;
   const uint32_t* rowr = rowl + (long)H * W;
-  uint32_t cl[SPT];
+  uint32_t cl[SPT], cr[SPT];
   uint32_t hl[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {  // all global loads first, so their latency overlaps
+    const int x = j * RJ_THREADS + tid;
+    cl[j] = (x < W) ? rowl[x] : RJ_EMPTY;
+    cr[j] = (x < W) ? rowr[x] : RJ_EMPTY;
+  }
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
     const int x = j * RJ_THREADS + tid;
-    const uint32_t c = (x < W) ? rowl[x] : RJ_EMPTY;
-    cl[j] = c;
+    const uint32_t c = cl[j];
     hl[j] = 0;
     if (c != RJ_EMPTY) {
       uint32_t h = rj_hash(c, hshift);
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
     const int x = j * RJ_THREADS + tid;
-    const uint32_t c = (x < W) ? rowr[x] : RJ_EMPTY;
+    const uint32_t c = cr[j];
     if (c != RJ_EMPTY) {
       uint32_t h = rj_hash(c, hshift);
       while (true) {
