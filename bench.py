@@ -81,21 +81,17 @@ def main():
     args = parse_args()
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    from opengpc_amd import dist as gdist
+
+    rank, world, local_rank = gdist.env_world()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    gdist.init("nccl", dev)  # nccl == RCCL on ROCm; no-op for a single process
 
     import opengpc_amd as g
     from opengpc_amd.synth import synth_batch
@@ -109,7 +105,7 @@ def main():
     ctx.reserve(W, H, B)
 
     # pair i -> rank i mod N  (weak scaling: B pairs per GPU per step)
-    indices = [rank + world * j for j in range(B)]
+    indices = gdist.shard_indices(rank, world, B)
     Lh, Rh = synth_batch(W, H, indices)
     d_L = torch.from_numpy(Lh).to(dev)
     d_R = torch.from_numpy(Rh).to(dev)
@@ -123,41 +119,28 @@ def main():
         ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, d_out.data_ptr(), cap,
                                d_counts.data_ptr(), d_ncand.data_ptr())
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def device_sync():
+        ctx.synchronize()  # the stream the kernels run on
+        torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-    ctx.synchronize()
-    torch.cuda.synchronize(dev)
+    device_sync()
 
     # HIP events around every launch of the pipeline's kernels, on the stream they run on
     ctx.enable_kernel_timing(True)
     ctx.reset_kernel_timing()
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = gdist.timed_steps(step, args.steps, device_sync)
     ktimes = ctx.kernel_times()
     ctx.enable_kernel_timing(False)
 
     counts = d_counts.cpu().numpy().astype(np.int64)
     ncand = d_ncand.cpu().numpy().astype(np.int64)
-    local = torch.tensor([elapsed, float(B), float(ncand.sum()), float(counts.sum())], dtype=torch.float64, device=dev)
-    if world > 1:
-        gathered = [torch.zeros_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)  # O(32 B) per rank over xGMI: timing/counters only
-        allr = torch.stack(gathered).cpu().numpy()
-    else:
-        allr = local.cpu().numpy()[None, :]
-    t_max = float(allr[:, 0].max())
-    pairs_per_step = float(allr[:, 1].sum())
+    # O(32 B) per rank over xGMI: timing / counters only, never pixel data
+    allr = gdist.gather_stats([elapsed, float(B), float(ncand.sum()), float(counts.sum())], device=dev).numpy()
+    job = gdist.reduce_job(torch.from_numpy(allr), args.steps, 2 * W * H)
+    t_max = job["t_max"]
+    pairs_per_step = job["pairs_per_step"]
 
     if rank == 0:
         mpix_per_step = 2.0 * W * H * pairs_per_step / 1e6
@@ -262,8 +245,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    gdist.finalize()
 
 
 if __name__ == "__main__":
