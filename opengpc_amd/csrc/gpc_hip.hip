@@ -16,6 +16,7 @@
 #include "k_global.h"
 #include "k_hash.h"
 #include "k_preprocess.h"
+#include "k_rowbucket.h"
 #include "k_rowjoin.h"
 #include "k_rowmatch.h"
 
@@ -62,7 +63,7 @@ struct gpc_hip_ctx {
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc;
 
-  bool force_lds_sort = false;  // GPC_HIP_ROWMATCH=lds: first-generation row kernel (A/B checks)
+  int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
 
   // timing
   bool timing = false;
@@ -227,13 +228,29 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     // LDS-sort kernel (k_rowmatch.h) remains for very wide images and for A/B checks.
     int spt = 1;
     while (spt * RJ_THREADS < W) spt <<= 1;
-    int log2s = 1;
-    while ((1 << log2s) <= 2 * (W - 2 * GPC_R)) ++log2s;
-    const size_t join_lds = (size_t)16 * (1u << log2s) + (size_t)4 * RJ_THREADS * spt;
-    const bool use_join = !c->force_lds_sort && spt <= 16 && join_lds <= 150 * 1024;
+    int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5
+    while ((1 << log2s) < 2 * (W - 2 * GPC_R)) ++log2s;
+    const size_t join_lds = (size_t)12 * ((1u << log2s) + 1) + (size_t)4 * RJ_THREADS * spt;
+    const bool use_join = c->row_kernel == 0 && spt <= 16 && join_lds <= 150 * 1024;
+    const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
+    const bool use_bucket = c->row_kernel == 1 && spt <= 16;
     {
       Timed t(c, KID_ROW_MATCH);
-      if (use_join) {
+      if (use_bucket) {
+        // third generation: counting (radix-bucket) join, k_rowbucket.h
+#define LAUNCH_BUCKET(SPT)                                                                         \
+  hipLaunchKernelGGL(gpc::k_row_bucket<SPT>, grid, dim3(RB_THREADS), bucket_lds, c->stream,        \
+                     (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                   \
+                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p)
+        switch (spt) {
+          case 1: LAUNCH_BUCKET(1); break;
+          case 2: LAUNCH_BUCKET(2); break;
+          case 4: LAUNCH_BUCKET(4); break;
+          case 8: LAUNCH_BUCKET(8); break;
+          default: LAUNCH_BUCKET(16); break;
+        }
+#undef LAUNCH_BUCKET
+      } else if (use_join) {
 #define LAUNCH_JOIN(SPT)                                                                          \
   hipLaunchKernelGGL(gpc::k_row_join<SPT>, grid, dim3(RJ_THREADS), join_lds, c->stream,           \
                      (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
@@ -402,8 +419,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   const char* rm = getenv("GPC_HIP_ROWMATCH");
-  c->force_lds_sort = rm && !strcmp(rm, "lds");
+  c->row_kernel = (rm && !strcmp(rm, "lds")) ? 2 : (rm && !strcmp(rm, "bucket")) ? 1 : 0;
   *out = c;
   return GPC_OK;
 }
@@ -733,6 +752,18 @@ int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR,
 }
 
 // ------------------------------------------------------------------ measurement
+
+#ifdef GPC_STAMPS
+// diagnostic build only: read and clear the s_memtime phase sums of k_row_join
+extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
+  if (!c || !out16) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpc::g_rj_stamps), 16 * sizeof(unsigned long long)));
+  unsigned long long zero[16] = {0};
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_rj_stamps), zero, sizeof zero));
+  return GPC_OK;
+}
+#endif
 
 int gpc_hip_enable_kernel_timing(gpc_hip_ctx* c, int enable) {
   if (!c) return GPC_E_INVALID;

@@ -81,8 +81,8 @@ def test_disparity_filter_and_flat_images(ctx, oracle, forest_paths):
     assert n == 0 and ncand == (0, 0)
 
 
-def test_first_generation_row_kernel_agrees(oracle, forest_paths):
-    """GPC_HIP_ROWMATCH=lds selects the LDS bitonic-sort row kernel; it must give identical supports."""
+def test_row_kernel_generations_agree(oracle, forest_paths):
+    """GPC_HIP_ROWMATCH selects the row kernel: join (default), bucket, lds -- identical supports."""
     code = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -98,8 +98,8 @@ for (W, H, fo) in [(1024, 436, "defaultZeroForest.txt"), (272, 40, "defaultTauFo
 print(out)
 ''' % (ROOT, ROOT)
     res = []
-    for mode in ("", "lds"):
+    for mode in ("", "bucket", "lds"):
         env = dict(os.environ, GPC_HIP_ROWMATCH=mode)
         res.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
                                   text=True).stdout.strip())
-    assert res[0] == res[1] and res[0].startswith("[(")
+    assert res[0] == res[1] == res[2] and res[0].startswith("[(")

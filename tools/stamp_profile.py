@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: builds libgpc_hip_stamps.so with -DGPC_STAMPS (s_memtime stamps at the phase
+boundaries of k_row_join) and prints each phase's SHARE of the workgroup's cycles.  The stamped
+build's run time is not representative (its fences forbid overlap); read shares only."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "gpurun_out", "libgpc_hip_stamps.so")
+PHASES = ["table init", "row loads", "insert left", "insert right", "decide", "sort", "lookup+store"]
+
+
+def main():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGPC_STAMPS",
+                           "-o", LIB, os.path.join(ROOT, "opengpc_amd", "csrc", "gpc_hip.hip")])
+    import opengpc_amd.capi as capi
+    capi.LIB_PATH = LIB
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_batch
+    W, H, B = 1024, 436, 32
+    ctx = g.Context(0)
+    ctx.load_forest(os.path.join(ROOT, "forests", "defaultZeroForest.txt"), W, H)
+    L, R = synth_batch(W, H, list(range(B)))
+    s = g.Settings.sparsematch()
+    cap = (W - 26) * (H - 26)
+    buf = (C.c_ulonglong * 16)()
+    ctx.match_batch(L, R, s, cap)
+    ctx.L.gpc_hip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    ctx.L.gpc_hip_debug_stamps(ctx.h, buf)
+    for _ in range(3):
+        ctx.match_batch(L, R, s, cap)
+    ctx.L.gpc_hip_debug_stamps(ctx.h, buf)
+    tot = sum(buf[i] for i in range(len(PHASES)))
+    nblk = 3 * B * len([y for y in range(H - 26) if (y & 63) == 5])
+    print("k_row_join phase shares (s_memtime ticks per workgroup, 100 MHz ticks x clock ratio):")
+    for i, name in enumerate(PHASES):
+        print("  %-14s %6.1f %%   %8.0f ticks/wg" % (name, 100.0 * buf[i] / tot, buf[i] / nblk))
+    print("  total %.0f ticks/wg" % (tot / nblk))
+
+
+if __name__ == "__main__":
+    main()
