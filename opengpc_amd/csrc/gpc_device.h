@@ -36,3 +36,44 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
+
+// Inclusive prefix sum across the 64 lanes of a wave with DPP only (no LDS traffic):
+// Kogge-Stone inside each row of 16 (row_shr 1,2,4,8), then row_bcast15 / row_bcast31.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);  // row_bcast31 -> rows 2,3
+  return v;
+}
+
+// Exclusive scan of arr[0 .. 256*SPT) in place by a 256-thread workgroup (thread t owns SPT
+// consecutive counters); arr[256*SPT] receives the total.  s_w: 4 words of scratch.
+// Ends with a barrier.
+template <int SPT>
+__device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_t* __restrict__ s_w, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t v[SPT];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    v[i] = arr[tid * SPT + i];
+    sum += v[i];
+  }
+  const uint32_t incl = wave_incl_scan(sum);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t base = incl - sum;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+    if (w < wave) base += s_w[w];
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    arr[tid * SPT + i] = base;
+    base += v[i];
+  }
+  if (tid == 255) arr[256 * SPT] = base;
+  __syncthreads();
+}

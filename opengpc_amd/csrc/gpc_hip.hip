@@ -228,9 +228,10 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     // LDS-sort kernel (k_rowmatch.h) remains for very wide images and for A/B checks.
     int spt = 1;
     while (spt * RJ_THREADS < W) spt <<= 1;
-    int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5
-    while ((1 << log2s) < 2 * (W - 2 * GPC_R)) ++log2s;
-    const size_t join_lds = (size_t)12 * ((1u << log2s) + 1) + (size_t)4 * RJ_THREADS * spt;
+    int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
+                    // S >= 256*spt because the rank phase reuses the accumulators as bucket counters
+    while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < RJ_THREADS * spt) ++log2s;
+    const size_t join_lds = (size_t)12 * ((1u << log2s) + 1);
     const bool use_join = c->row_kernel == 0 && spt <= 16 && join_lds <= 150 * 1024;
     const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
     const bool use_bucket = c->row_kernel == 1 && spt <= 16;

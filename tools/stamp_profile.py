@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "gpurun_out", "libgpc_hip_stamps.so")
-PHASES = ["table init", "row loads", "insert left", "insert right", "decide", "sort", "lookup+store"]
+PHASES = ["loads+init", "insert left", "lookups+adds", "decide", "rank count", "rank scan+scatter", "rank walk+store"]
 
 
 def main():
