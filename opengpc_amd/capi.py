@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpc_hip.so")
+# GPC_HIP_LIB overrides the library path (used only to A/B differently compiled builds of this library)
+LIB_PATH = os.environ.get("GPC_HIP_LIB") or os.path.join(HERE, "libgpc_hip.so")
 
 MAX_TESTS = 32
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_NO_FOREST, E_FOREST_RANGE, E_IO, E_UNSUPPORTED = range(9)

@@ -13,12 +13,19 @@
 #define GPC_STAT_NCAND 0
 #define GPC_STAT_LASTROW 1
 
-// hash kernel tile: 256 x 16 outputs (4 pixels per lane), smooth staged with a 16-byte aligned 16-pixel apron
+// hash kernel tile: 256 x HT_Y outputs (4 pixels per lane, 4 rows per wave), smooth staged with a 16-byte aligned 16-pixel apron
 #define HT_X 256
-#define HT_Y 16
+// (tile height, workgroup size) measured on MI355X, k_hash per 64 images 1024x436:
+// (16,256) 123 us, (16,512) 100 us, (32,512) 93 us, (64,1024) 94 us, (32,256) 129 us, (8,256) 151 us
+#ifndef HT_Y
+#define HT_Y 32
+#endif
+#ifndef HT_THREADS
+#define HT_THREADS 512
+#endif
 #define HT_APRON 16
 #define HT_STRIDE (HT_X + 2 * HT_APRON)  // 288 bytes per LDS row
-#define HT_ROWS (HT_Y + 2 * GPC_R)       // 42 rows
+#define HT_ROWS (HT_Y + 2 * GPC_R)       // 58 rows
 #define HT_COPY (HT_ROWS * HT_STRIDE)    // bytes of one (shifted) copy of the window
 
 // Passed BY VALUE as a kernel argument: every field is a 32-bit scalar the compiler keeps in

@@ -201,7 +201,7 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
 #define LAUNCH_HASH(TAU, DENSE)                                                                \
-  hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE>), grid, dim3(256), 0, c->stream, d_smooth, d_grad, \
+  hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
                      d_cand, d_codes, W, H, c->forest, st)
   if (tau && dense) LAUNCH_HASH(true, true);
   else if (tau) LAUNCH_HASH(true, false);

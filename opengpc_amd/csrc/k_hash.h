@@ -5,7 +5,7 @@
 // (inference.hpp:274-290).
 //
 // Layout of the work (gfx950):
-//   * a 256-thread workgroup owns a 256 x 16 output tile; the (256+32) x (16+26) smooth
+//   * a 512-thread workgroup owns a 256 x 32 output tile; the (256+32) x (32+26) smooth
 //     window is staged once into LDS with 16-byte coalesced loads;
 //   * a LANE owns 4 horizontally adjacent pixels, a WAVE one 256-pixel row segment per step
 //     and 4 rows in total.  The window is kept in LDS FOUR times, copy s shifted left by s
@@ -71,12 +71,12 @@ __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int 
 // smooth, grad, candmap: [nimg][H][W]; codes: [nimg][H][W] u32
 // candmap == nullptr: candidate <=> grad != 0 inside the margin (preprocessImage's mask).
 template <bool TAU, bool DENSE>
-__global__ __launch_bounds__(256) void k_hash(const uint8_t* __restrict__ smooth,
+__global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
                                               GpcForestDev f, int32_t* __restrict__ img_stats) {
-  constexpr int RPW = HT_Y / 4;
+  constexpr int RPW = HT_Y / (HT_THREADS / 64);
   __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
   __shared__ int s_cnt, s_last;
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_hash(const uint8_t* __restrict__ smooth
   // ---- stage the smooth window; linear addressing like the reference's unaligned loads,
   //      bytes outside the buffer read as 0
   //      copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
-  for (int c = tid; c < HT_ROWS * (HT_STRIDE / 16); c += 256) {
+  for (int c = tid; c < HT_ROWS * (HT_STRIDE / 16); c += HT_THREADS) {
     const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
     const long k = (long)(ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
     uint4 v = make_uint4(0, 0, 0, 0);
