@@ -41,7 +41,7 @@ typedef enum {
   GPC_E_NO_FOREST = 5,    /* match/hash called before gpc_hip_set_forest                 */
   GPC_E_FOREST_RANGE = 6, /* a test offset leaves the 27x27 patch                        */
   GPC_E_IO = 7,           /* forest file could not be opened / parsed                    */
-  GPC_E_UNSUPPORTED = 8   /* e.g. useHashtable=true (hashmatch.hpp) -- not on this path  */
+  GPC_E_UNSUPPORTED = 8   /* reserved: a setting this build cannot honour                */
 } gpc_status;
 
 /* == ndb::Support, lib/gpc/buffer.hpp:91-97 (12 bytes) */
@@ -61,7 +61,7 @@ typedef struct {
   int32_t disp_high;          /* dispHigh_, default 128                    */
   int32_t vertical_tolerance; /* verticalTolerance_, default 1             */
   int32_t epipolar_mode;      /* epipolarMode_, default 0                  */
-  int32_t use_hashtable;      /* useHashtable_: must be 0 on this path     */
+  int32_t use_hashtable;      /* useHashtable_: 1 = ndb::Hashmatch matcher */
   int32_t num_threads;        /* numThreads_: accepted, ignored            */
 } gpc_settings;
 

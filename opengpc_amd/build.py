@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpc_hip.so")
 SOURCES = ["gpc_hip.hip"]
-HEADERS = ["gpc_device.h", "k_preprocess.h", "k_hash.h", "k_rowmatch.h", "k_rowjoin.h", "k_rowbucket.h", "k_global.h",
+HEADERS = ["gpc_device.h", "k_preprocess.h", "k_hash.h", "k_rowmatch.h", "k_rowjoin.h", "k_rowbucket.h", "k_global.h", "k_hashtable.h",
            os.path.join("..", "..", "include", "gpc_hip.h")]
 
 

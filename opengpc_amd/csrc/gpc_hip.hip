@@ -15,6 +15,7 @@
 #include "gpc_device.h"
 #include "k_global.h"
 #include "k_hash.h"
+#include "k_hashtable.h"
 #include "k_preprocess.h"
 #include "k_rowbucket.h"
 #include "k_rowjoin.h"
@@ -61,7 +62,7 @@ struct gpc_hip_ctx {
 
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
-  DevBuf gkeys[2], gvals[2], ghist, gmisc;
+  DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2];
 
   int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
 
@@ -172,6 +173,8 @@ bool next_int(const char*& p, int& v) {
 
 int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
                      void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
+int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+                        void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
 
 // raw0/raw1 device pointers; fills smooth, grad for npairs*sides images
 int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1, int W, int H,
@@ -215,8 +218,8 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
 // code images of npairs pairs -> supports / correspondences in d_out
 int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
               void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
-  if (s->use_hashtable) return GPC_E_UNSUPPORTED;
   const int apply_filter = (mode == 0);
+  if (s->use_hashtable) return run_hashtable_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
   if (s->epipolar_mode) {
     CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)W * H * npairs));
     CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * npairs * 2));
@@ -347,10 +350,78 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
   return GPC_OK;
 }
 
+// useHashtable mode (hashmatch.hpp): stable radix sort by bucket id + one thread per bucket (k_hashtable.h)
+int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+                        void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
+  const size_t n = (size_t)W * H;
+  const int nmax = 2 * (W - 2 * GPC_R) * (H - 2 * GPC_R);
+  const int nblk = (nmax + GS_TILE - 1) / GS_TILE;
+  const int nmblk = (nmax + 255) / 256;
+  for (int i = 0; i < 2; ++i) {
+    CHK(ensure(c, c->hkeys[i], sizeof(uint32_t) * (size_t)nmax));
+    CHK(ensure(c, c->hvals[i], sizeof(uint32_t) * (size_t)nmax));
+  }
+  CHK(ensure(c, c->gkeys[0], sizeof(uint32_t) * (size_t)nmax));
+  CHK(ensure(c, c->gvals[0], sizeof(uint32_t) * (size_t)nmax));
+  CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * nblk + nmblk)));
+  CHK(ensure(c, c->gmisc, sizeof(int32_t) * 16));
+  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
+  int32_t* hist = (int32_t*)c->ghist.p;
+  int32_t* blkcnt = hist + (size_t)256 * nblk;
+  int32_t* gmisc = (int32_t*)c->gmisc.p;
+  int32_t* rowcnt = (int32_t*)c->rowcnt.p;
+  const int apply_filter = (mode == 0);
+  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  uint32_t* codes0 = (uint32_t*)c->gkeys[0].p;
+  uint32_t* kv0 = (uint32_t*)c->gvals[0].p;
+  uint32_t* keys[2] = {(uint32_t*)c->hkeys[0].p, (uint32_t*)c->hkeys[1].p};
+  uint32_t* vals[2] = {(uint32_t*)c->hvals[0].p, (uint32_t*)c->hvals[1].p};
+  for (int p = 0; p < npairs; ++p) {
+    const uint32_t* codes = (const uint32_t*)c->codes.p + (size_t)p * 2 * n;
+    const int32_t* stats = (const int32_t*)c->stats.p + (size_t)p * 2 * GPC_STAT_STRIDE;
+    dim3 rgrid(H - 2 * GPC_R, 2);
+    {
+      Timed t(c, KID_GLOBAL_KEYS);
+      hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, rowcnt, stats, gmisc);
+      hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+                         (const int32_t*)rowcnt, stats, codes0, kv0, gmisc);
+      hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)codes0,
+                         (const uint32_t*)kv0, (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, keys[0], vals[0]);
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      Timed t(c, KID_GLOBAL_SORT);
+      for (int pass = 0; pass < 3; ++pass) {  // 214673 < 2^18: three 8-bit digits
+        const int src = pass & 1, dst = src ^ 1;
+        hipLaunchKernelGGL(gpc::k_g_hist, dim3(nblk), dim3(GS_THREADS), 0, c->stream, (const uint32_t*)keys[src],
+                           (const int32_t*)gmisc, 8 * pass, hist, nblk);
+        hipLaunchKernelGGL(gpc::k_g_scan, dim3(1), dim3(1024), 0, c->stream, hist, 256 * nblk);
+        hipLaunchKernelGGL(gpc::k_g_scatter, dim3(nblk), dim3(GS_THREADS), 0, c->stream,
+                           (const uint32_t*)keys[src], (const uint32_t*)vals[src], keys[dst], vals[dst],
+                           (const int32_t*)gmisc, 8 * pass, (const int32_t*)hist, nblk);
+      }
+      HIPCHK(c, hipGetLastError());
+    }
+    {
+      Timed t(c, KID_GLOBAL_MATCH);
+      hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)keys[1],
+                         (const uint32_t*)vals[1], (const uint32_t*)codes0, (const uint32_t*)kv0,
+                         (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, s->disp_high, s->vertical_tolerance,
+                         apply_filter, blkcnt, mode, (void*)nullptr, 0, (int32_t*)nullptr, stats, (int32_t*)nullptr);
+      hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)keys[1],
+                         (const uint32_t*)vals[1], (const uint32_t*)codes0, (const uint32_t*)kv0,
+                         (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, s->disp_high, s->vertical_tolerance,
+                         apply_filter, blkcnt, mode, (void*)((char*)d_out + (size_t)p * cap * esz), cap, d_counts + p,
+                         stats, d_ncand ? d_ncand + 2 * p : nullptr);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  return GPC_OK;
+}
+
 int check_settings(const gpc_settings* s) {
   if (!s) return GPC_E_INVALID;
   if (s->gradient_threshold < 0 || s->gradient_threshold > 255) return GPC_E_INVALID;
-  if (s->use_hashtable) return GPC_E_UNSUPPORTED;
   return GPC_OK;
 }
 
@@ -434,7 +505,8 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
-                    &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc};
+                    &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
+                    &c->hvals[0], &c->hvals[1]};
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto& s : c->free_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

@@ -366,6 +366,85 @@ int gpc_oracle_find_correspondences(const uint64_t* ss, const int32_t* sk, int n
   return n;
 }
 
+/* ------------------------------------------------------------------ */
+/* Hashmatch -- lib/gpc/hashmatch.hpp, driven by inference.hpp:204-225  */
+/* ------------------------------------------------------------------ */
+
+#define HM_BUCKETS 214673 /* inference.hpp:210 */
+#define HM_CAP 10         /* terminateAfter, hashmatch.hpp:93 */
+
+typedef struct {
+  uint64_t state;
+  int32_t k;
+  int32_t src; /* srcDescr */
+} hm_elem;
+
+typedef struct {
+  hm_elem e[HM_CAP];
+  int n;
+} hm_bucket;
+
+/* OrderedLinkedList::insert (hashmatch.hpp:91-131): full buckets drop the value; otherwise it
+ * goes behind every element <= it, so equal states keep their insertion order. */
+static void hm_insert(hm_bucket* b, hm_elem v) {
+  if (b->n >= HM_CAP) return;
+  int pos = 0;
+  while (pos < b->n && b->e[pos].state <= v.state) ++pos;
+  for (int i = b->n; i > pos; --i) b->e[i] = b->e[i - 1];
+  b->e[pos] = v;
+  b->n++;
+}
+
+/* OrderedLinkedList::getDuplicates (hashmatch.hpp:162-197) on the ordered array. */
+static int hm_pairs(const hm_bucket* b, int W, gpc_oracle_corr* out) {
+  int n = 0, i = 0;
+  const hm_elem* a = b->e;
+  while (i < b->n) {
+    int p = i;
+    ++i;
+    if (i < b->n && a[p].state == a[i].state) {
+      if (a[p].src != a[i].src) {
+        int emit = 0;
+        if (i + 1 < b->n) {
+          emit = a[i + 1].state != a[i].state;          /* third element differs (:175) */
+        } else {
+          emit = 1;                                     /* no third element (:180) */
+        }
+        if (emit) {
+          out[n].sx = a[p].k % W;
+          out[n].sy = a[p].k / W;
+          out[n].tx = a[i].k % W;
+          out[n].ty = a[i].k / W;
+          ++n;
+        }
+        if (i + 1 < b->n && i + 2 >= b->n) return n;    /* "last triplet": leave the bucket (:178) */
+      } else if (i + 1 < b->n && a[i].src != a[i + 1].src) {
+        ++i;                                            /* skip over a false pair (:188-192) */
+      }
+    }
+  }
+  return n;
+}
+
+int gpc_oracle_hash_correspondences(const uint64_t* ss, const int32_t* sk, int ns,
+                                    const uint64_t* ts, const int32_t* tk, int nt,
+                                    int W, gpc_oracle_corr* out) {
+  hm_bucket* tab = (hm_bucket*)calloc(HM_BUCKETS, sizeof(hm_bucket));
+  for (int i = 0; i < ns; ++i) { /* all source descriptors first (inference.hpp:213-216) */
+    hm_elem v = {ss[i], sk[i], 1};
+    hm_insert(&tab[ss[i] % HM_BUCKETS], v);
+  }
+  for (int i = 0; i < nt; ++i) {
+    hm_elem v = {ts[i], tk[i], 0};
+    hm_insert(&tab[ts[i] % HM_BUCKETS], v);
+  }
+  int n = 0;
+  for (int b = 0; b < HM_BUCKETS; ++b)
+    if (tab[b].n) n += hm_pairs(&tab[b], W, out + n);
+  free(tab);
+  return n;
+}
+
 /* rectifiedMatch filter -- lib/gpc/inference.hpp:384-391 */
 int gpc_oracle_rectified_filter(const gpc_oracle_corr* c, int n,
                                 const gpc_oracle_settings* s, gpc_oracle_support* out) {
@@ -407,7 +486,9 @@ int gpc_oracle_match_pair(const uint8_t* rawL, const uint8_t* rawR, int W, int H
   }
   int capc = cnt[0] > 0 ? cnt[0] : 1;
   gpc_oracle_corr* corr = (gpc_oracle_corr*)malloc((size_t)capc * sizeof(gpc_oracle_corr));
-  int nc = gpc_oracle_find_correspondences(state[0], mask[0], cnt[0], state[1], mask[1], cnt[1], W, corr);
+  int nc = s->use_hashtable
+               ? gpc_oracle_hash_correspondences(state[0], mask[0], cnt[0], state[1], mask[1], cnt[1], W, corr)
+               : gpc_oracle_find_correspondences(state[0], mask[0], cnt[0], state[1], mask[1], cnt[1], W, corr);
   int m = gpc_oracle_rectified_filter(corr, nc, s, out);
   if (n_cand_l) *n_cand_l = cnt[0];
   if (n_cand_r) *n_cand_r = cnt[1];

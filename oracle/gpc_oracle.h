@@ -49,6 +49,7 @@ typedef struct {
   int32_t disp_high;
   int32_t vertical_tolerance;
   int32_t epipolar_mode;
+  int32_t use_hashtable; /* 0: sort-match (findCorrespondences), 1: ndb::Hashmatch */
 } gpc_oracle_settings;
 
 /* synthetic inputs, SURVEY.md 8(d) */
@@ -76,6 +77,11 @@ void gpc_oracle_descriptors(const uint32_t* codes, const int32_t* mask, int n, i
                             int epipolar, uint64_t* state);
 /* findCorrespondences on (state, linear index) sets; returns count */
 int gpc_oracle_find_correspondences(const uint64_t* ss, const int32_t* sk, int ns,
+                                    const uint64_t* ts, const int32_t* tk, int nt,
+                                    int W, gpc_oracle_corr* out);
+/* Hashmatch path of depthPriorFast (inference.hpp:204-225, hashmatch.hpp): 214673 buckets of
+ * ordered lists capped at 10 entries, pair extraction per bucket.  Same in/out as above. */
+int gpc_oracle_hash_correspondences(const uint64_t* ss, const int32_t* sk, int ns,
                                     const uint64_t* ts, const int32_t* tk, int nt,
                                     int W, gpc_oracle_corr* out);
 int gpc_oracle_rectified_filter(const gpc_oracle_corr* c, int n,

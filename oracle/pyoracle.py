@@ -36,6 +36,7 @@ class Settings(C.Structure):
         ("disp_high", C.c_int32),
         ("vertical_tolerance", C.c_int32),
         ("epipolar_mode", C.c_int32),
+        ("use_hashtable", C.c_int32),
     ]
 
 
@@ -80,6 +81,7 @@ class Oracle:
         L.gpc_oracle_read_forest.restype = C.c_int
         L.gpc_oracle_preprocess.restype = C.c_int
         L.gpc_oracle_find_correspondences.restype = C.c_int
+        L.gpc_oracle_hash_correspondences.restype = C.c_int
         L.gpc_oracle_rectified_filter.restype = C.c_int
         L.gpc_oracle_match_pair.restype = C.c_int
 
@@ -156,6 +158,16 @@ class Oracle:
             _u64p(ss), _i32p(sk), len(ss), _u64p(ts), _i32p(tk), len(ts), W, out.ctypes.data_as(C.c_void_p))
         return out[:n].copy()
 
+    def hash_correspondences(self, ss, sk, ts, tk, W):
+        ss = np.ascontiguousarray(ss, np.uint64)
+        ts = np.ascontiguousarray(ts, np.uint64)
+        sk = np.ascontiguousarray(sk, np.int32)
+        tk = np.ascontiguousarray(tk, np.int32)
+        out = np.empty(max(len(ss), len(ts), 1), CORR_DTYPE)
+        n = self.lib.gpc_oracle_hash_correspondences(
+            _u64p(ss), _i32p(sk), len(ss), _u64p(ts), _i32p(tk), len(ts), W, out.ctypes.data_as(C.c_void_p))
+        return out[:n].copy()
+
     def rectified_filter(self, corr, settings):
         corr = np.ascontiguousarray(corr)
         out = np.empty(max(len(corr), 1), SUPPORT_DTYPE)
@@ -176,9 +188,9 @@ class Oracle:
         return out[:n].copy(), nl.value, nr.value
 
 
-def sparsematch_settings(thr=5, disp_high=128, vtol=0, epipolar=True):
+def sparsematch_settings(thr=5, disp_high=128, vtol=0, epipolar=True, hashtable=False):
     """Settings of samples/sparsematch.cpp:29-34."""
-    return Settings(thr, disp_high, vtol, int(epipolar))
+    return Settings(thr, disp_high, vtol, int(epipolar), int(hashtable))
 
 
 def supports_fnv(oracle, supp):
@@ -200,6 +212,7 @@ class Ref:
         L.gpc_ref_arr2ind.restype = C.c_int
         L.gpc_ref_is_sse.restype = C.c_int
         L.gpc_ref_cpu_baseline_pair.restype = C.c_int
+        L.gpc_ref_hashmatch.restype = C.c_int
 
     @staticmethod
     def available():
@@ -262,3 +275,14 @@ class Ref:
             settings.gradient_threshold, settings.disp_high, settings.vertical_tolerance,
             settings.epipolar_mode, _i32p(out), W * H, C.byref(t_pre), C.byref(t_match))
         return out[:n].copy(), t_pre.value, t_match.value
+
+    def hashmatch(self, ss, sk, ts, tk):
+        """The reference's ndb::Hashmatch (hashmatch.hpp) driven as inference.hpp:204-225 does.
+        Returns an int32 [n][2] array of (source k, target k)."""
+        ss = np.ascontiguousarray(ss, np.uint64)
+        ts = np.ascontiguousarray(ts, np.uint64)
+        sk = np.ascontiguousarray(sk, np.int32)
+        tk = np.ascontiguousarray(tk, np.int32)
+        out = np.empty((max(len(ss), len(ts), 1), 2), np.int32)
+        n = self.lib.gpc_ref_hashmatch(_u64p(ss), _i32p(sk), len(ss), _u64p(ts), _i32p(tk), len(ts), _i32p(out))
+        return out[:n].copy()

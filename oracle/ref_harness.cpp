@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "gpc/filter.hpp"
+#include "gpc/hashmatch.hpp"  // templates only; its buffer.hpp include is guarded out like filter.hpp's
 
 extern "C" {
 
@@ -58,6 +59,35 @@ void gpc_ref_hash(const uint8_t* smooth, const uint8_t* grad, uint32_t* codes,
     std::vector<int> t(tau, tau + ntests);
     ndb::gpcFilterTau(const_cast<uint8_t*>(smooth), grad, codes, mask, t, idx, w, h, nthreads);
   }
+}
+
+// ndb::Hashmatch<T> (hashmatch.hpp:217-272) is a template over the element type; it is
+// instantiated here with a harness-owned element that offers the operators the template uses
+// (<=, ==, !=, %, diffImgs) and driven exactly like depthPriorFast does (inference.hpp:204-225):
+// 214673 buckets, all source elements first, then all targets, then getDuplicates.
+struct HmElem {
+  uint64_t state;
+  int32_t k;
+  bool src;
+  bool operator==(const HmElem& d) const { return state == d.state; }
+  bool operator!=(const HmElem& d) const { return state != d.state; }
+  bool operator<=(const HmElem& d) const { return state <= d.state; }
+  bool diffImgs(const HmElem& d) { return src != d.src; }
+  int operator%(const int& d) const { return state % d; }
+};
+
+int gpc_ref_hashmatch(const uint64_t* ss, const int32_t* sk, int ns, const uint64_t* ts, const int32_t* tk,
+                      int nt, int32_t* out_pairs /* 2 ints per pair */) {
+  ndb::Hashmatch<HmElem> hm(214673, ns + nt);
+  for (int i = 0; i < ns; ++i) { HmElem e = {ss[i], sk[i], true}; hm.insert(e); }
+  for (int i = 0; i < nt; ++i) { HmElem e = {ts[i], tk[i], false}; hm.insert(e); }
+  std::vector<std::pair<HmElem, HmElem>> corr;
+  hm.getDuplicates(corr);
+  for (size_t i = 0; i < corr.size(); ++i) {
+    out_pairs[2 * i] = corr[i].first.k;
+    out_pairs[2 * i + 1] = corr[i].second.k;
+  }
+  return (int)corr.size();
 }
 
 int gpc_ref_is_sse(void) {

@@ -189,7 +189,7 @@ def test_capacity_and_errors(ctx, oracle, forest_paths):
     with pytest.raises(g.GpcError):  # width not a multiple of 16
         ctx.preprocess(np.zeros((64, 100), np.uint8), 5)
     s = gpu_settings(True)
-    s.use_hashtable = 1
+    s.gradient_threshold = 300
     with pytest.raises(g.GpcError):
         ctx.match_pair(L, R, s)
 
@@ -214,3 +214,42 @@ def test_batch_equals_single(ctx, oracle, forest_paths):
             so, nl, nr = oracle.match_pair(Ls[i], Rs[i], f, sparsematch_settings())
             assert np.array_equal(single, so.astype(single.dtype))
             assert np.median(single["d"]) == 8 + i  # a few chance collisions carry other disparities
+
+
+@pytest.mark.parametrize("W,H", [(96, 64), (176, 67), (1024, 436)])
+@pytest.mark.parametrize("epipolar", [True, False])
+def test_hashtable_mode_vs_oracle(ctx, oracle, forest_paths, W, H, epipolar):
+    """settings.useHashtable_ = true: ndb::Hashmatch semantics (214673 buckets, 10 per bucket,
+    pair/triplet rules, bucket order).  The oracle's restatement is checked against the reference's
+    own template in tests/test_oracle_vs_ref.py."""
+    import opengpc_amd as g
+    rng = np.random.default_rng(77)
+    rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+    ctx.load_forest(forest_paths["zero"], W, H)
+    for trial in range(2):
+        base = images(W + 64, H, 60 + trial)[1]
+        d = int(rng.integers(0, 40))
+        L = np.ascontiguousarray(base[:, 32:32 + W])
+        R = np.ascontiguousarray(base[:, 32 + d:32 + d + W])
+        for disp_high, vtol in ((128, 0), (16, 1)):
+            so, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, disp_high, vtol, epipolar, True))
+            sg, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, disp_high, vtol, epipolar, True, 1))
+            assert st == 0 and (nl, nr) == tuple(ncand)
+            assert n == len(so)
+            assert np.array_equal(sg, so.astype(sg.dtype))
+
+
+def test_hashtable_mode_bucket_overflow_and_triplets(ctx, oracle, forest_paths):
+    """Striped images: few distinct codes, so buckets overflow their 10-element cap and the
+    pair/triplet rules of getDuplicates decide."""
+    import opengpc_amd as g
+    W, H = 256, 64
+    rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+    ctx.load_forest(forest_paths["zero"], W, H)
+    img = np.tile((np.arange(W) // 3 * 37 % 256).astype(np.uint8), (H, 1))
+    img2 = np.roll(img, 5, axis=1)
+    for ep in (True, False):
+        so, nl, nr = oracle.match_pair(img, img2, f, sparsematch_settings(5, 128, 1, ep, True))
+        sg, n, ncand, st = ctx.match_pair(img, img2, g.Settings(5, 128, 1, ep, True, 1))
+        assert (nl, nr) == tuple(ncand) and nl > 0
+        assert n == len(so) and np.array_equal(sg, so.astype(sg.dtype))

@@ -88,3 +88,33 @@ def test_hash_threads_identical(ref, oracle, forest_paths):
     img = images(W, H, 7)[1]
     smooth, grad, _ = oracle.preprocess(img, 5)
     assert np.array_equal(ref.hash(smooth, grad, f, 1), ref.hash(smooth, grad, f, 4))
+
+
+def test_hashmatch_restatement_vs_reference_template(ref, oracle):
+    """oracle hash_correspondences == the reference's ndb::Hashmatch<T> (hashmatch.hpp) driven as
+    depthPriorFast does: colliding buckets (multiples of 214673), overflow beyond 10, triplets."""
+    rng = np.random.default_rng(1)
+    pool = np.array([5, 5 + 214673, 5 + 2 * 214673, 7, 9, 9 + 214673 * 3, 11, (3 << 32) | 7], np.uint64)
+    for trial in range(400):
+        ns, nt = rng.integers(0, 40, 2)
+        ss, ts = rng.choice(pool, ns), rng.choice(pool, nt)
+        sk = rng.permutation(1000)[:ns].astype(np.int32)
+        tk = (rng.permutation(1000)[:nt] + 2000).astype(np.int32)
+        a = oracle.hash_correspondences(ss, sk, ts, tk, 100000)
+        b = ref.hashmatch(ss, sk, ts, tk)
+        assert [(int(c["sx"]) + 100000 * int(c["sy"]), int(c["tx"]) + 100000 * int(c["ty"])) for c in a] == \
+               [(int(x), int(y)) for x, y in b]
+
+
+def test_hashmatch_on_real_descriptors(ref, oracle, forest_paths):
+    W, H = 1024, 436
+    L, R = oracle.synth_pair(W, H, 0, 24)
+    rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+    pl, pr = oracle.preprocess(L, 5), oracle.preprocess(R, 5)
+    cl, cr = oracle.hash(pl[0], pl[1], f), oracle.hash(pr[0], pr[1], f)
+    for epi in (True, False):
+        sl, sr = oracle.descriptors(cl, pl[2], W, epi), oracle.descriptors(cr, pr[2], W, epi)
+        a = oracle.hash_correspondences(sl, pl[2], sr, pr[2], W)
+        b = ref.hashmatch(sl, pl[2], sr, pr[2])
+        assert len(a) == len(b) and len(a) > 200000
+        assert np.array_equal(a["sx"] + W * a["sy"], b[:, 0]) and np.array_equal(a["tx"] + W * a["ty"], b[:, 1])
