@@ -38,16 +38,25 @@ __device__ __forceinline__ uint32_t swar_ge(uint32_t a, uint32_t b) {
   return (x & b) | (~x & d);                   // top bits differ -> b's top bit decides (v_bfi_b32)
 }
 
-// _mm_subs_epi8(b, tau) on 4 packed bytes: signed saturating subtract (filter.hpp:649-651)
-__device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, int tau) {
-  uint32_t r = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int v = (int)(int8_t)(b >> (8 * j)) - tau;
-    v = min(max(v, -128), 127);
-    r |= (uint32_t)(v & 0xFF) << (8 * j);
-  }
-  return r;
+// _mm_subs_epi8(b, tau) on 4 packed bytes: signed saturating subtract (filter.hpp:649-651).
+// An int8 value placed in the HIGH byte of a 16-bit lane saturates under a saturating 16-bit
+// subtract exactly when the int8 subtraction would (v_pk_sub_i16 with clamp), so the even and
+// the odd bytes take one packed op each: perm, pk_sub, and, pk_sub, perm = 5 VALU per 4 pixels.
+// tau_hi = (tau & 0xFF) << 8 in both 16-bit halves.
+typedef short gpc_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
+  const uint32_t xe = __builtin_amdgcn_perm(0u, b, 0x020C000Cu);  // [0, b0, 0, b2]
+  const uint32_t xo = b & 0xFF00FF00u;                             // [0, b1, 0, b3]
+  gpc_short2 t, e, o;
+  __builtin_memcpy(&t, &tau_hi, 4);
+  __builtin_memcpy(&e, &xe, 4);
+  __builtin_memcpy(&o, &xo, 4);
+  e = __builtin_elementwise_sub_sat(e, t);
+  o = __builtin_elementwise_sub_sat(o, t);
+  uint32_t re, ro;
+  __builtin_memcpy(&re, &e, 4);
+  __builtin_memcpy(&ro, &o, 4);
+  return __builtin_amdgcn_perm(ro, re, 0x07030501u);  // high bytes back in place: [e.1, o.1, e.3, o.3]
 }
 
 // One test for RPW rows: shift the 4 compare bits of every row into its byte plane
@@ -62,7 +71,7 @@ __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int 
   for (int r = 0; r < RPW; ++r) {
     uint32_t a = pa[r * (HT_STRIDE / 4)];
     uint32_t b = pb[r * (HT_STRIDE / 4)];
-    if (TAU) b = subs_epi8x4(b, tau);
+    if (TAU) b = subs_epi8x4(b, (uint32_t)(tau & 0xFF) * 0x01000100u);
     const uint32_t ge = swar_ge(a, b);
     plane[r] = (ge & SW_H) | ((plane[r] >> 1) & SW_M);
   }
