@@ -94,6 +94,11 @@ int gpc_hip_synchronize(gpc_hip_ctx* ctx);
  * entry points below grow them on demand, which costs a hipMalloc + sync). */
 int gpc_hip_reserve(gpc_hip_ctx* ctx, int width, int height, int max_pairs);
 
+/* Page-locked host memory (hipHostMalloc) for the host-buffer entry points: with pageable
+ * buffers the PCIe copies run at a fraction of the link rate.  Free with gpc_hip_host_free. */
+int gpc_hip_host_alloc(gpc_hip_ctx* ctx, uint64_t bytes, void** ptr);
+int gpc_hip_host_free(gpc_hip_ctx* ctx, void* ptr);
+
 /* ---- forest ------------------------------------------------------------------ */
 /* Forest::readForest (inference.hpp:404-446): parses the text forest for an image of
  * `width` x `height`.  Host only.  A missing file yields GPC_E_IO and an empty mask of

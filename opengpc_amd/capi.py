@@ -67,7 +67,7 @@ _lib = None
 SYMBOLS = [
     "gpc_hip_abi_version", "gpc_hip_status_string", "gpc_hip_device_count", "gpc_hip_create",
     "gpc_hip_destroy", "gpc_hip_last_error", "gpc_hip_set_stream", "gpc_hip_synchronize",
-    "gpc_hip_reserve", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
+    "gpc_hip_reserve", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_enable_kernel_timing", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
@@ -94,6 +94,8 @@ def load():
     L.gpc_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.gpc_hip_synchronize.argtypes = [C.c_void_p]
     L.gpc_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.gpc_hip_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.gpc_hip_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.gpc_hip_read_forest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FilterMask)]
     L.gpc_hip_parse_forest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FilterMask)]
     L.gpc_hip_set_forest.argtypes = [C.c_void_p, C.POINTER(FilterMask)]
@@ -155,9 +157,13 @@ class Context:
         _check(self.L, None, self.L.gpc_hip_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._pinned = []
 
     def close(self):
         if self.h:
+            for p in self._pinned:
+                self.L.gpc_hip_host_free(self.h, p)
+            self._pinned = []
             self.L.gpc_hip_destroy(self.h)
             self.h = None
 
@@ -179,6 +185,16 @@ class Context:
 
     def reserve(self, width, height, max_pairs):
         self._ck(self.L.gpc_hip_reserve(self.h, width, height, max_pairs))
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array in page-locked host memory (gpc_hip_host_alloc); freed with the context."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._ck(self.L.gpc_hip_host_alloc(self.h, max(nbytes, 1), C.byref(p)))
+        self._pinned.append(p)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def set_forest(self, fm):
         self._ck(self.L.gpc_hip_set_forest(self.h, C.byref(fm)))
@@ -243,11 +259,12 @@ class Context:
         self._ck(st, allow=(E_CAPACITY,))
         return out[:min(n.value, cap)].copy(), n.value, (nl.value, nr.value), st
 
-    def match_batch(self, rawL, rawR, settings, cap):
+    def match_batch(self, rawL, rawR, settings, cap, out=None):
         rawL = np.ascontiguousarray(rawL, np.uint8)
         rawR = np.ascontiguousarray(rawR, np.uint8)
         P, H, W = rawL.shape
-        out = np.empty((P, cap), SUPPORT_DTYPE)
+        if out is None:
+            out = np.empty((P, cap), SUPPORT_DTYPE)
         counts = np.empty(P, np.int32)
         ncand = np.empty((P, 2), np.int32)
         st = self.L.gpc_hip_match_batch(self.h, _ptr(rawL), _ptr(rawR), W, H, P, C.byref(settings), _ptr(out), cap,

@@ -547,6 +547,19 @@ int gpc_hip_reserve(gpc_hip_ctx* c, int W, int H, int max_pairs) {
   return GPC_OK;
 }
 
+int gpc_hip_host_alloc(gpc_hip_ctx* c, uint64_t bytes, void** ptr) {
+  if (!c || !ptr || bytes == 0) return GPC_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+  return GPC_OK;
+}
+
+int gpc_hip_host_free(gpc_hip_ctx* c, void* ptr) {
+  if (!c || !ptr) return GPC_E_INVALID;
+  HIPCHK(c, hipHostFree(ptr));
+  return GPC_OK;
+}
+
 // ------------------------------------------------------------------ forest
 
 int gpc_hip_parse_forest(const char* text, int W, int H, gpc_filter_mask* fm) {

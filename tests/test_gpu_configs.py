@@ -103,3 +103,43 @@ print(out)
         res.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
                                   text=True).stdout.strip())
     assert res[0] == res[1] == res[2] and res[0].startswith("[(")
+
+
+def test_edge_inputs(ctx, oracle, forest_paths):
+    """Empty and ragged inputs: no candidates at all, candidates on one side only, the smallest
+    legal image, an odd height (box writes one more row), thresholds at both ends."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    fz = forest_paths["zero"]
+
+    def both(L, R, thr=5, epi=True, ht=False):
+        H, W = L.shape
+        rc, f = oracle.read_forest(fz, W, H)
+        ctx.load_forest(fz, W, H)
+        want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(thr, 128, 1, epi, ht))
+        got, n, ncand, st = ctx.match_pair(L, R, g.Settings(thr, 128, 1, epi, ht, 1))
+        assert st == 0 and (nl, nr) == ncand and n == len(want)
+        assert np.array_equal(got, want.astype(got.dtype))
+        return n, ncand
+
+    L, R = synth_pair(48, 30, 1, 3)                      # smallest legal size: 22 x 4 candidate window
+    both(L, R)
+    L, R = synth_pair(160, 101, 2, 7)                    # odd height
+    for epi in (True, False):
+        for ht in (False, True):
+            both(L, R, epi=epi, ht=ht)
+    zero = np.zeros((64, 96), np.uint8)
+    Ln, Rn = synth_pair(96, 64, 3, 4)
+    assert both(zero, zero) == (0, (0, 0))
+    for epi in (True, False):
+        for ht in (False, True):
+            assert both(Ln, zero, epi=epi, ht=ht)[0] == 0    # nothing on the right (n_t = 0)
+            assert both(zero, Rn, epi=epi, ht=ht)[0] == 0    # nothing on the left
+    both(Ln, Rn, thr=0)                                  # every pixel with any gradient is a candidate
+    both(Ln, Rn, thr=181)                                # largest threshold before the int16 wrap
+    both(Ln, Rn, thr=255)                                # thr^2 wraps negative: everything is a candidate
+
+
+def test_very_wide_image_falls_back_to_lds_sort_kernel(ctx, oracle, forest_paths):
+    """W > 4096 exceeds the join kernel's instantiations; the LDS-sort row kernel takes over."""
+    check_pair(ctx, oracle, forest_paths["zero"], 4112, 34, 6, 21)

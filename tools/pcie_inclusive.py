@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer batch entry point (gpc_hip_match_batch): raw pairs in
+host memory -> supports in host memory, synchronous.  Never used as bench.py's `value`."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import opengpc_amd as g  # noqa: E402
+from opengpc_amd.synth import synth_batch  # noqa: E402
+
+
+def main():
+    W, H = 1024, 436
+    ctx = g.Context(0)
+    ctx.load_forest(os.path.join(ROOT, "forests", "defaultZeroForest.txt"), W, H)
+    s = g.Settings.sparsematch()
+    res = []
+    for B in (1, 32):
+        for pinned in (False, True):
+            L, R = synth_batch(W, H, list(range(B)))
+            cap = 300000
+            out = None
+            if pinned:
+                Lp, Rp = ctx.pinned_empty(L.shape, np.uint8), ctx.pinned_empty(R.shape, np.uint8)
+                Lp[:] = L
+                Rp[:] = R
+                L, R = Lp, Rp
+                out = ctx.pinned_empty((B, cap), g.SUPPORT_DTYPE)
+            for _ in range(2):
+                o, counts, ncand, st = ctx.match_batch(L, R, s, cap, out=out)
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o, counts, ncand, st = ctx.match_batch(L, R, s, cap, out=out)
+            dt = (time.perf_counter() - t0) / n
+            rec = {"pairs": B, "host_buffers": "pinned (gpc_hip_host_alloc)" if pinned else "pageable",
+                   "ms_per_call": round(dt * 1e3, 3), "Mpix_per_s": round(2.0 * W * H * B / dt / 1e6, 1),
+                   "bytes_in": int(L.nbytes + R.nbytes), "bytes_out": int(counts.sum()) * 12,
+                   "note": "one synchronous call = H2D + pipeline + D2H of the valid supports"}
+            res.append(rec)
+            print(json.dumps(rec))
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pcie_inclusive.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
