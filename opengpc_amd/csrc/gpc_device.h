@@ -56,10 +56,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
-// Exclusive scan of arr[0 .. 256*SPT) in place by a 256-thread workgroup (thread t owns SPT
-// consecutive counters); arr[256*SPT] receives the total.  s_w: 4 words of scratch.
+// Exclusive scan of arr[0 .. NT*SPT) in place by an NT-thread workgroup (thread t owns SPT
+// consecutive counters); arr[NT*SPT] receives the total.  s_w: NT/64 words of scratch.
 // Ends with a barrier.
-template <int SPT>
+template <int SPT, int NT = 256>
 __device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_t* __restrict__ s_w, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   uint32_t v[SPT];
@@ -74,13 +74,13 @@ __device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_
   __syncthreads();
   uint32_t base = incl - sum;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
+  for (int w = 0; w < NT / 64 - 1; ++w)
     if (w < wave) base += s_w[w];
 #pragma unroll
   for (int i = 0; i < SPT; ++i) {
     arr[tid * SPT + i] = base;
     base += v[i];
   }
-  if (tid == 255) arr[256 * SPT] = base;
+  if (tid == NT - 1) arr[NT * SPT] = base;
   __syncthreads();
 }

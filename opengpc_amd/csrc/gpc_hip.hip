@@ -227,21 +227,25 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     int disp_high = s->disp_high;
     if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
     dim3 grid(H - 2 * GPC_R, npairs);
-    // second-generation kernel: LDS hash join + register bitonic sort (k_rowjoin.h); the
-    // LDS-sort kernel (k_rowmatch.h) remains for very wide images and for A/B checks.
+    // join kernel (k_rowjoin.h): NT threads x SPT pixel slots per thread cover a row; wide rows
+    // get more threads (their table leaves room for only 1-3 workgroups per CU).  The counting-join
+    // (k_rowbucket.h) and LDS-sort (k_rowmatch.h) kernels remain for A/B checks / very wide images.
     int spt = 1;
-    while (spt * RJ_THREADS < W) spt <<= 1;
+    while (spt * RB_THREADS < W) spt <<= 1;   // bucket variant: 256 threads
+    int jspt = 1, jnt = 256;
+    while (jspt * jnt < W && jspt < 4) jspt <<= 1;
+    while (jspt * jnt < W && jnt < 1024) jnt <<= 1;
     int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
-                    // S >= 256*spt because the rank phase reuses the accumulators as bucket counters
-    while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < RJ_THREADS * spt) ++log2s;
+                    // S >= NT*SPT because the rank phase reuses the accumulators as bucket counters
+    while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < jnt * jspt) ++log2s;
     const size_t join_lds = (size_t)12 * ((1u << log2s) + 1);
-    const bool use_join = c->row_kernel == 0 && spt <= 16 && join_lds <= 150 * 1024;
+    const bool use_join = c->row_kernel == 0 && jspt * jnt >= W && join_lds <= 150 * 1024;
     const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
     const bool use_bucket = c->row_kernel == 1 && spt <= 16;
     {
       Timed t(c, KID_ROW_MATCH);
       if (use_bucket) {
-        // third generation: counting (radix-bucket) join, k_rowbucket.h
+        // counting (radix-bucket) join, k_rowbucket.h
 #define LAUNCH_BUCKET(SPT)                                                                         \
   hipLaunchKernelGGL(gpc::k_row_bucket<SPT>, grid, dim3(RB_THREADS), bucket_lds, c->stream,        \
                      (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                   \
@@ -255,17 +259,15 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
         }
 #undef LAUNCH_BUCKET
       } else if (use_join) {
-#define LAUNCH_JOIN(SPT)                                                                          \
-  hipLaunchKernelGGL(gpc::k_row_join<SPT>, grid, dim3(RJ_THREADS), join_lds, c->stream,           \
+#define LAUNCH_JOIN(SPT, NT)                                                                      \
+  hipLaunchKernelGGL((gpc::k_row_join<SPT, NT>), grid, dim3(NT), join_lds, c->stream,             \
                      (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
                      (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s)
-        switch (spt) {
-          case 1: LAUNCH_JOIN(1); break;
-          case 2: LAUNCH_JOIN(2); break;
-          case 4: LAUNCH_JOIN(4); break;
-          case 8: LAUNCH_JOIN(8); break;
-          default: LAUNCH_JOIN(16); break;
-        }
+        if (jnt == 1024) LAUNCH_JOIN(4, 1024);
+        else if (jnt == 512) LAUNCH_JOIN(4, 512);
+        else if (jspt == 4) LAUNCH_JOIN(4, 256);
+        else if (jspt == 2) LAUNCH_JOIN(2, 256);
+        else LAUNCH_JOIN(1, 256);
 #undef LAUNCH_JOIN
       } else {
         const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
@@ -486,11 +488,8 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   const int max_dyn = 160 * 1024 - 2048;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_match),
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   const char* rm = getenv("GPC_HIP_ROWMATCH");

@@ -106,20 +106,22 @@ __device__ __forceinline__ uint32_t rj_find(const uint32_t* __restrict__ t_key, 
 // codes:   [npairs*2][H][W]   (image 2p = left, 2p+1 = right)
 // staged:  [npairs][H][W]     packed (xL | xR<<16), first rowcnt entries of each row valid
 // rowcnt:  [npairs][H]
-// grid: (H - 26, npairs); NB = 256*SPT >= W; table of S = 1 << log2s slots,
+// grid: (H - 26, npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
 //       S >= max(2*(W-26), NB)   (only left codes are inserted: load factor <= 0.5)
 // dynamic LDS: 12*(S+1) bytes  (24 KiB for W = 1024: 6 workgroups per CU)
-template <int SPT>
-__global__ __launch_bounds__(RJ_THREADS) void k_row_join(
+// Wide rows use more threads per row instead of more pixel slots per thread, so that the one
+// or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
+template <int SPT, int NT>
+__global__ __launch_bounds__(NT) void k_row_join(
     const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s) {
-  constexpr int NB = RJ_THREADS * SPT;
-  constexpr int RSHIFT = 31 - (8 + (SPT == 1 ? 0 : SPT == 2 ? 1 : SPT == 4 ? 2 : SPT == 8 ? 3 : 4));
+  constexpr int NB = NT * SPT;
+  constexpr int RSHIFT = 31 - ((NT == 256 ? 8 : NT == 512 ? 9 : 10) + (SPT == 1 ? 0 : SPT == 2 ? 1 : SPT == 4 ? 2 : SPT == 8 ? 3 : 4));
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
   __shared__ int s_max_r, s_tail_cnt;
   __shared__ unsigned s_tail_minx;
-  __shared__ uint32_t s_w[RJ_THREADS / 64];
+  __shared__ uint32_t s_w[NT / 64];
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
   uint32_t* t_wl = rj_lds + (S + 1);      // [S]   left  accumulators (count << 16) + x
@@ -142,11 +144,11 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
     uint32_t cr[SPT];
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-      const int x = j * RJ_THREADS + tid;
+      const int x = j * NT + tid;
       cl[j] = (x < W) ? rowl[x] : RJ_EMPTY;
       cr[j] = (x < W) ? rowr[x] : RJ_EMPTY;
     }
-    for (int i = tid; i < 3 * (S + 1); i += RJ_THREADS) rj_lds[i] = 0u;
+    for (int i = tid; i < 3 * (S + 1); i += NT) rj_lds[i] = 0u;
     if (tid == 0) {
       s_max_r = -1;
       s_tail_cnt = 0;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
     }
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-      const uint32_t x = (uint32_t)(j * RJ_THREADS + tid);
+      const uint32_t x = (uint32_t)(j * NT + tid);
       hl[j] = 0u;
       if (kl[j]) {
         hl[j] = rj_find(t_key, kl[j], f0l[j], h0l[j], smask);  // a left code is always found
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
     for (int j = 0; j < SPT; ++j)
       if (kr[j] && kr[j] == tail_key) {
         atomicAdd(&s_tail_cnt, 1);
-        atomicMin(&s_tail_minx, (unsigned)(j * RJ_THREADS + tid));
+        atomicMin(&s_tail_minx, (unsigned)(j * NT + tid));
       }
   }
   __syncthreads();
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
       const bool tail = tail_row && kl[j] == tail_key;
       bool good = ((wl >> 16) == 1u) && (tail ? (s_tail_cnt == 2) : ((wr >> 16) == 1u));
       xr[j] = tail ? s_tail_minx : (wr & 0xFFFFu);
-      if (good && apply_filter) good = abs((int)(j * RJ_THREADS + tid) - (int)xr[j]) <= disp_high;
+      if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
       ok[j] = good;
     }
   }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
   RJ_STAMP(3);
 
   // ---- 4. output position = rank of the code among the row's matches (counting rank)
-  for (int i = tid; i <= NB; i += RJ_THREADS) r_cnt[i] = 0u;
+  for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
   __syncthreads();
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
   }
   __syncthreads();
   RJ_STAMP(4);
-  block_exscan<SPT>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b, r_cnt[NB] = number of matches
+  block_exscan<SPT, NT>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b, r_cnt[NB] = number of matches
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if (ok[j]) r_key[r_cnt[rb[j]] + rs[j]] = cl[j];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_row_join(
       const uint32_t s0 = r_cnt[rb[j]], e0 = r_cnt[rb[j] + 1];
       uint32_t rank = s0;
       for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cl[j]);
-      dst[rank] = (uint32_t)(j * RJ_THREADS + tid) | (xr[j] << 16);
+      dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
     }
 #ifdef GPC_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
