@@ -212,6 +212,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, W, H)
 
+        # BASELINE configs[1] taken literally: ONE pair per step (launch/occupancy-bound, reported
+        # beside the batched headline, never instead of it)
+        single = None
+        if world == 1:
+            def step1():
+                ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, 1, settings, d_out.data_ptr(), cap,
+                                       d_counts.data_ptr(), d_ncand.data_ptr())
+            for _ in range(5):
+                step1()
+            device_sync()
+            n1 = 200
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                step1()
+            device_sync()
+            dt1 = (time.perf_counter() - t1) / n1
+            single = {"ms_per_pair": round(dt1 * 1e3, 4), "Mpix_per_s": round(2.0 * W * H / dt1 / 1e6, 1),
+                      "note": "one 1024x436 pair per step, back-to-back steps, inputs/outputs in HBM"}
+
         line = {
             "metric": "Mpix/s hashed+matched (1024x436 pair)",
             "value": round(value, 1),
@@ -239,6 +258,7 @@ def main():
             "verified_vs_oracle": verified,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "single_pair": single,
         }
         if cpu:
             line["speedup_vs_cpu_1thread"] = round(value / cpu["value"], 1)

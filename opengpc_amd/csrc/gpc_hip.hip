@@ -64,6 +64,7 @@ struct gpc_hip_ctx {
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2];
 
+  int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
   int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
 
   // timing
@@ -235,6 +236,11 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     int jspt = 1, jnt = 256;
     while (jspt * jnt < W && jspt < 4) jspt <<= 1;
     while (jspt * jnt < W && jnt < 1024) jnt <<= 1;
+    if (c->join_nt) {  // tuning override (GPC_HIP_JOIN_NT): threads per row, slots per thread follow
+      jnt = c->join_nt;
+      jspt = 1;
+      while (jspt * jnt < W && jspt < 4) jspt <<= 1;
+    }
     int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
                     // S >= NT*SPT because the rank phase reuses the accumulators as bucket counters
     while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < jnt * jspt) ++log2s;
@@ -263,11 +269,9 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
   hipLaunchKernelGGL((gpc::k_row_join<SPT, NT>), grid, dim3(NT), join_lds, c->stream,             \
                      (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
                      (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s)
-        if (jnt == 1024) LAUNCH_JOIN(4, 1024);
-        else if (jnt == 512) LAUNCH_JOIN(4, 512);
-        else if (jspt == 4) LAUNCH_JOIN(4, 256);
-        else if (jspt == 2) LAUNCH_JOIN(2, 256);
-        else LAUNCH_JOIN(1, 256);
+        if (jnt == 1024) { if (jspt == 4) LAUNCH_JOIN(4, 1024); else if (jspt == 2) LAUNCH_JOIN(2, 1024); else LAUNCH_JOIN(1, 1024); }
+        else if (jnt == 512) { if (jspt == 4) LAUNCH_JOIN(4, 512); else if (jspt == 2) LAUNCH_JOIN(2, 512); else LAUNCH_JOIN(1, 512); }
+        else { if (jspt == 4) LAUNCH_JOIN(4, 256); else if (jspt == 2) LAUNCH_JOIN(2, 256); else LAUNCH_JOIN(1, 256); }
 #undef LAUNCH_JOIN
       } else {
         const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
@@ -492,6 +496,8 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  const char* jn = getenv("GPC_HIP_JOIN_NT");
+  if (jn && (atoi(jn) == 256 || atoi(jn) == 512 || atoi(jn) == 1024)) c->join_nt = atoi(jn);
   const char* rm = getenv("GPC_HIP_ROWMATCH");
   c->row_kernel = (rm && !strcmp(rm, "lds")) ? 2 : (rm && !strcmp(rm, "bucket")) ? 1 : 0;
   *out = c;

@@ -130,30 +130,29 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_hist(const uint32_t* __restric
   hist[tid * nblk + blk] = s_hist[tid];
 }
 
-// exclusive scan of `total` ints in place; one workgroup of 1024 threads
+// exclusive scan of `total` ints in place; one workgroup of 1024 threads = 16 waves, each wave
+// owning a contiguous slice: pass 1 sums the slice (coalesced loads, no cross-lane work), the 16
+// slice totals are combined through LDS, pass 2 rescans the slice with a DPP wave scan and a
+// scalar carry.  (~100 KB of counters per radix pass: latency-, not bandwidth-bound.)
 __global__ __launch_bounds__(1024) void k_g_scan(int32_t* __restrict__ data, int total) {
-  __shared__ int s_wsum[16];
-  __shared__ int s_carry;
+  __shared__ int s_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
+  const int per = (((total + 15) / 16) + 63) / 64 * 64;
+  const int beg = wave * per;
+  const int end = min(beg + per, total);
+  int acc = 0;
+  for (int i = beg + lane; i < end; i += 64) acc += data[i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) s_tot[wave] = acc;
   __syncthreads();
-  for (int base = 0; base < total; base += 1024) {
-    const int i = base + tid;
-    const int v = (i < total) ? data[i] : 0;
-    int incl = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-    const int carry = s_carry;
-    if (i < total) data[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = carry + woff + incl;
-    __syncthreads();
+  int carry = 0;
+  for (int w = 0; w < wave; ++w) carry += s_tot[w];
+  for (int i0 = beg; i0 < end; i0 += 64) {
+    const int i = i0 + lane;
+    const int v = (i < end) ? data[i] : 0;
+    const int incl = (int)wave_incl_scan((uint32_t)v);
+    if (i < end) data[i] = carry + incl - v;
+    carry += __builtin_amdgcn_readlane(incl, 63);
   }
 }
 
