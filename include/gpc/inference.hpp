@@ -99,6 +99,14 @@ inline ContextHolder& holder() {
     const char* dev = std::getenv("GPC_HIP_DEVICE");
     const int st = gpc_hip_create(dev ? std::atoi(dev) : 0, &h.ctx);
     if (st != GPC_OK) fail(st, nullptr, "gpc_hip_create");
+    // Like the reference, the arithmetic variant is a build-time choice of the CALLER's
+    // translation unit: -D_INTRINSICS_SSE (the reference's default, samples/CMakeLists.txt:13-17)
+    // selects the SSE-exact kernels, its absence the *Naive ones (filter.hpp:157-282).
+#ifdef _INTRINSICS_SSE
+    gpc_hip_set_arithmetic(h.ctx, GPC_ARITH_SSE);
+#else
+    gpc_hip_set_arithmetic(h.ctx, GPC_ARITH_NAIVE);
+#endif
   }
   return h;
 }

@@ -94,6 +94,14 @@ int gpc_hip_synchronize(gpc_hip_ctx* ctx);
  * entry points below grow them on demand, which costs a hipMalloc + sync). */
 int gpc_hip_reserve(gpc_hip_ctx* ctx, int width, int height, int max_pairs);
 
+/* The reference has two arithmetic variants chosen at BUILD time (samples/CMakeLists.txt:13-20):
+ * SSE=ON (-D_INTRINSICS_SSE, the default and the parity target of this library) and SSE=OFF
+ * (boxNaive / sobelNaive / gpcFilter(Tau)Naive, filter.hpp:157-282), which produce different
+ * smooth images, masks and codes.  A context starts in GPC_ARITH_SSE. */
+#define GPC_ARITH_SSE 0
+#define GPC_ARITH_NAIVE 1
+int gpc_hip_set_arithmetic(gpc_hip_ctx* ctx, int mode);
+
 /* Page-locked host memory (hipHostMalloc) for the host-buffer entry points: with pageable
  * buffers the PCIe copies run at a fraction of the link rate.  Free with gpc_hip_host_free. */
 int gpc_hip_host_alloc(gpc_hip_ctx* ctx, uint64_t bytes, void** ptr);

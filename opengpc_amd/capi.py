@@ -67,7 +67,7 @@ _lib = None
 SYMBOLS = [
     "gpc_hip_abi_version", "gpc_hip_status_string", "gpc_hip_device_count", "gpc_hip_create",
     "gpc_hip_destroy", "gpc_hip_last_error", "gpc_hip_set_stream", "gpc_hip_synchronize",
-    "gpc_hip_reserve", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
+    "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_enable_kernel_timing", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
@@ -94,6 +94,7 @@ def load():
     L.gpc_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.gpc_hip_synchronize.argtypes = [C.c_void_p]
     L.gpc_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.gpc_hip_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
     L.gpc_hip_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.gpc_hip_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.gpc_hip_read_forest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FilterMask)]
@@ -195,6 +196,10 @@ class Context:
         self._pinned.append(p)
         buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def set_arithmetic(self, naive):
+        """False: the reference's default SSE build; True: its SSE=OFF (*Naive) arithmetic."""
+        self._ck(self.L.gpc_hip_set_arithmetic(self.h, 1 if naive else 0))
 
     def set_forest(self, fm):
         self._ck(self.L.gpc_hip_set_forest(self.h, C.byref(fm)))

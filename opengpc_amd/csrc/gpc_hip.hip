@@ -56,8 +56,10 @@ struct gpc_hip_ctx {
   hipStream_t stream = nullptr;
   char err[256] = {0};
 
+  bool naive = false;  // gpc_hip_set_arithmetic: the reference's SSE=OFF (*Naive) arithmetic
   bool have_forest = false;
-  GpcForestDev forest;
+  GpcForestDev forest;        // tests in file order (SSE bit placement)
+  GpcForestDev forest_naive;  // tests reversed: slot u = test T-1-u lands on bit u (MSB-first codes), raw int tau
   int forest_w = 0, forest_h = 0;
 
   // workspaces
@@ -185,13 +187,16 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   CHK(ensure(c, c->smooth, n * nimg));
   CHK(ensure(c, c->grad, n * nimg));
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
-  // threshold^2 passes through _mm_set1_epi16 in the reference (filter.hpp:418)
-  const int thr_sq = (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
+  // threshold^2 passes through _mm_set1_epi16 in the SSE build (filter.hpp:418); sobelNaive keeps the int (:159)
+  const int thr_sq = c->naive ? (thr & 0xFF) * (thr & 0xFF) : (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
   dim3 grid((W / 8 + PP_TX - 1) / PP_TX, (H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS), nimg);
   Timed t(c, KID_PREPROCESS);
-  hipLaunchKernelGGL(gpc::k_preprocess, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
-                     (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq,
-                     (int32_t*)c->stats.p);
+  if (c->naive)
+    hipLaunchKernelGGL(gpc::k_preprocess<true>, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
+                       (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p);
+  else
+    hipLaunchKernelGGL(gpc::k_preprocess<false>, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
+                       (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p);
   HIPCHK(c, hipGetLastError());
   return GPC_OK;
 }
@@ -204,13 +209,20 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
-#define LAUNCH_HASH(TAU, DENSE)                                                                \
-  hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, c->forest, st)
-  if (tau && dense) LAUNCH_HASH(true, true);
-  else if (tau) LAUNCH_HASH(true, false);
-  else if (dense) LAUNCH_HASH(false, true);
-  else LAUNCH_HASH(false, false);
+#define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
+  hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
+                     d_cand, d_codes, W, H, NAIVE ? c->forest_naive : c->forest, st)
+  if (c->naive) {
+    if (tau && dense) LAUNCH_HASH(true, true, true);
+    else if (tau) LAUNCH_HASH(true, false, true);
+    else if (dense) LAUNCH_HASH(false, true, true);
+    else LAUNCH_HASH(false, false, true);
+  } else {
+    if (tau && dense) LAUNCH_HASH(true, true, false);
+    else if (tau) LAUNCH_HASH(true, false, false);
+    else if (dense) LAUNCH_HASH(false, true, false);
+    else LAUNCH_HASH(false, false, false);
+  }
 #undef LAUNCH_HASH
   HIPCHK(c, hipGetLastError());
   return GPC_OK;
@@ -552,6 +564,12 @@ int gpc_hip_reserve(gpc_hip_ctx* c, int W, int H, int max_pairs) {
   return GPC_OK;
 }
 
+int gpc_hip_set_arithmetic(gpc_hip_ctx* c, int mode) {
+  if (!c || (mode != GPC_ARITH_SSE && mode != GPC_ARITH_NAIVE)) return GPC_E_INVALID;
+  c->naive = (mode == GPC_ARITH_NAIVE);
+  return GPC_OK;
+}
+
 int gpc_hip_host_alloc(gpc_hip_ctx* c, uint64_t bytes, void** ptr) {
   if (!c || !ptr || bytes == 0) return GPC_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -619,8 +637,9 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
   if (fm->num_tests < 0 || fm->num_tests > GPC_MAX_TESTS) return GPC_E_INVALID;
   CHK(check_dims(fm->width, fm->height));
   const int W = fm->width;
-  GpcForestDev f;
+  GpcForestDev f, fn;
   memset(&f, 0, sizeof f);
+  memset(&fn, 0, sizeof fn);
   for (int t = 0; t < fm->num_tests; ++t) {
     int d[4];
     for (int q = 0; q < 2; ++q) {
@@ -640,10 +659,15 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
     }
     f.off[t] = (offs[0] & 0xFFFF) | (offs[1] << 16);
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
+    // gpcFilterNaive shifts the code left per test: test t ends on bit T-1-t (filter.hpp:245-249)
+    const int u = fm->num_tests - 1 - t;
+    fn.off[u] = f.off[t];
+    fn.tau[u] = fm->tau[t];              // gpcFilterTauNaive uses the int as is (:276)
   }
-  f.num_tests = fm->num_tests;
-  f.type = fm->type ? 1 : 0;
+  f.num_tests = fn.num_tests = fm->num_tests;
+  f.type = fn.type = fm->type ? 1 : 0;
   c->forest = f;
+  c->forest_naive = fn;
   c->forest_w = fm->width;
   c->forest_h = fm->height;
   c->have_forest = true;

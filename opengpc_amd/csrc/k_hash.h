@@ -59,9 +59,28 @@ __device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
   return __builtin_amdgcn_perm(ro, re, 0x07030501u);  // high bytes back in place: [e.1, o.1, e.3, o.3]
 }
 
+// unsigned saturating add of a uniform constant to 4 packed bytes (same high-byte trick, v_pk_add_u16 clamp)
+typedef unsigned short gpc_ushort2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t uaddsat_x4(uint32_t x, uint32_t t_hi) {
+  const uint32_t xe = __builtin_amdgcn_perm(0u, x, 0x020C000Cu);
+  const uint32_t xo = x & 0xFF00FF00u;
+  gpc_ushort2 t, e, o;
+  __builtin_memcpy(&t, &t_hi, 4);
+  __builtin_memcpy(&e, &xe, 4);
+  __builtin_memcpy(&o, &xo, 4);
+  e = __builtin_elementwise_add_sat(e, t);
+  o = __builtin_elementwise_add_sat(o, t);
+  uint32_t re, ro;
+  __builtin_memcpy(&re, &e, 4);
+  __builtin_memcpy(&ro, &o, 4);
+  return __builtin_amdgcn_perm(ro, re, 0x07030501u);
+}
+
 // One test for RPW rows: shift the 4 compare bits of every row into its byte plane
 // (new bit enters at bit 7, so the first test of a plane ends up on bit 0 after 8 steps).
-template <bool TAU, int RPW>
+// NAIVE (the reference's SSE=OFF build): the tau predicate is the plain integer a > b - tau
+// (filter.hpp:276):  tau >= 1:  sat(a + tau - 1) >= b ;  tau <= 0:  a > sat(b - tau).
+template <bool TAU, bool NAIVE, int RPW>
 __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int lanebase, int packed, int tau,
                                           uint32_t (&plane)[RPW]) {
   // packed: dword offsets (copy select + row + column) of the two taps
@@ -71,15 +90,28 @@ __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int 
   for (int r = 0; r < RPW; ++r) {
     uint32_t a = pa[r * (HT_STRIDE / 4)];
     uint32_t b = pb[r * (HT_STRIDE / 4)];
-    if (TAU) b = subs_epi8x4(b, (uint32_t)(tau & 0xFF) * 0x01000100u);
-    const uint32_t ge = swar_ge(a, b);
+    uint32_t ge;  // bit 7 of each byte = NOT(code bit)
+    if (TAU && NAIVE) {
+      if (tau >= 1) {  // wave-uniform
+        const uint32_t c = uaddsat_x4(a, (uint32_t)min(tau - 1, 255) * 0x01000100u);
+        ge = ~swar_ge(b, c);  // code bit = (c >= b)
+      } else {
+        ge = swar_ge(a, uaddsat_x4(b, (uint32_t)min(-tau, 255) * 0x01000100u));
+      }
+    } else {
+      if (TAU) b = subs_epi8x4(b, (uint32_t)(tau & 0xFF) * 0x01000100u);
+      ge = swar_ge(a, b);
+    }
     plane[r] = (ge & SW_H) | ((plane[r] >> 1) & SW_M);
   }
 }
 
 // smooth, grad, candmap: [nimg][H][W]; codes: [nimg][H][W] u32
 // candmap == nullptr: candidate <=> grad != 0 inside the margin (preprocessImage's mask).
-template <bool TAU, bool DENSE>
+// NAIVE: gpcFilterNaive / gpcFilterTauNaive (filter.hpp:237-281) -- code bits MSB-first
+// (test t on bit T-1-t), every candidate row hashed, no 16-pixel group skip.  The host passes the
+// tests in reverse order (slot u = test T-1-u) so that slot u lands on bit u.
+template <bool TAU, bool DENSE, bool NAIVE>
 __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
@@ -150,10 +182,10 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     // the reference skips 16-pixel groups (4 lanes here) without any gradient byte (filter.hpp:566)
     const unsigned long long gm = __ballot(g4 != 0);
     const bool group_any = ((gm >> (lane & 60)) & 0xFull) != 0;
-    const bool rows_ok = y >= GPC_R && y < H - 15;  // gpcFilterSegment(13, height-15) :602
+    const bool rows_ok = y >= GPC_R && y < (NAIVE ? H - GPC_R : H - 15);  // gpcFilterSegment(13, height-15) :602
     candbits[r] = cb;
-    rowdo[r] = inimg && rows_ok && group_any;
-    any = any || (DENSE ? rowdo[r] : (cb != 0 && rowdo[r]));
+    rowdo[r] = inimg && rows_ok && (NAIVE || group_any);
+    any = any || ((DENSE && !NAIVE) ? rowdo[r] : (cb != 0 && rowdo[r]));
   }
 
   // ---- the tests, in the reference's byte planes: P0 = tests 0..7, (test 8), P1 = 9..16,
@@ -170,32 +202,52 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     uint32_t p0[RPW], p1[RPW], p2[RPW], p3[RPW], p8[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) p0[r] = p1[r] = p2[r] = p3[r] = p8[r] = ~0u;  // "ge" planes: all-ones = no bit
-    if (T > 0) {
+    if (NAIVE) {
+      // slot u -> bit u: four full byte planes, no special test 8
+      if (T > 0) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
-    }
-    if (T > 8) fern_test<TAU, RPW>(tile, lanebase, f.off[8], f.tau[8], p8);
-    if (T > 9) {
+        for (int t = 0; t < 8; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
+      }
+      if (T > 8) {
 #pragma unroll
-      for (int t = 9; t < 17; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
-    }
-    if (T > 17) {
+        for (int t = 8; t < 16; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
+      }
+      if (T > 16) {
 #pragma unroll
-      for (int t = 17; t < 25; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
-    }
-    if (T > 25) {
+        for (int t = 16; t < 24; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
+      }
+      if (T > 24) {
 #pragma unroll
-      for (int t = 25; t < 32; ++t) fern_test<TAU, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+        for (int t = 24; t < 32; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+      }
+    } else {
+      if (T > 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
+      }
+      if (T > 8) fern_test<TAU, false, RPW>(tile, lanebase, f.off[8], f.tau[8], p8);
+      if (T > 9) {
+#pragma unroll
+        for (int t = 9; t < 17; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
+      }
+      if (T > 17) {
+#pragma unroll
+        for (int t = 17; t < 25; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
+      }
+      if (T > 25) {
+#pragma unroll
+        for (int t = 25; t < 32; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+      }
     }
     // test 8 is OR-ed into bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask)
     const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       // planes hold "b >= a"; the code bit is its complement.  P3 saw 7 tests: one more shift.
-      const uint32_t q0 = ~p0[r] | ((~p8[r] >> 7) & m8);
+      const uint32_t q0 = NAIVE ? ~p0[r] : (~p0[r] | ((~p8[r] >> 7) & m8));
       const uint32_t q1 = ~p1[r];
       const uint32_t q2 = ~p2[r];
-      const uint32_t q3 = (~p3[r] >> 1) & SW_M;
+      const uint32_t q3 = NAIVE ? ~p3[r] : ((~p3[r] >> 1) & SW_M);
       // transpose 4 planes x 4 pixels -> 4 codes (byte k of code j = plane k, byte j)
       const uint32_t lo01 = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
       const uint32_t hi01 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
@@ -219,7 +271,8 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t c = rowdo[r] ? code[r][j] : 0u;
-        op[j] = DENSE ? c : (((candbits[r] >> j) & 1u) ? c : GPC_NOCAND);
+        const bool is_cand = (candbits[r] >> j) & 1u;
+        op[j] = DENSE ? ((NAIVE && !is_cand) ? 0u : c) : (is_cand ? c : GPC_NOCAND);
       }
       *reinterpret_cast<uint4*>(out + (long)y * W + x0) = o;
     }

@@ -21,18 +21,22 @@ __device__ __forceinline__ int third(int s) { return (s * 21846) >> 16; }  // mu
 __device__ __forceinline__ int ninth(int s) { return (s * 7282) >> 16; }   // mulhi_epi16(s,7282)
 
 struct PreRow {
-  int h[8];  // third(p[x-1]+p[x]+p[x+1]) for the 8 strip pixels
-  int a[6];  // raw pixels x0-1 .. x0+4 (the 4 Sobel decisions of the strip need these)
+  int h[8];   // SSE: third(p[x-1]+p[x]+p[x+1]) for the 8 strip pixels; NAIVE: the plain 3-sum
+  int a[10];  // raw pixels x0-1 .. x0+8 (SSE needs the first 6: 4 Sobel decisions per strip)
 };
 
 // Linear addressing as in the reference: the byte left of column 0 is the previous row's
 // last byte, the byte right of column W-1 the next row's first (filter.hpp:325-327).
+template <bool NAIVE>
 __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, long n, int W, int H,
                                              int r, int x0, PreRow& o) {
   int p[10];
   if (r < 0 || r >= H) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) p[i] = 0;
+    // linear addressing: the byte "left of" column 0 of the row below the image is the image's
+    // last byte (the naive filters' window at position (H-1)*W reaches it)
+    if (r == H && x0 == 0) p[0] = raw[n - 1];
   } else {
     long k = (long)r * W + x0;
     uint2 v = *reinterpret_cast<const uint2*>(raw + k);
@@ -45,13 +49,16 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o.h[i] = third(p[i] + p[i + 1] + p[i + 2]);
+  for (int i = 0; i < 8; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) o.a[i] = p[i];
+  for (int i = 0; i < 10; ++i) o.a[i] = p[i];
 }
 
 // raw0/raw1: [npairs][H][W] for side 0 / 1 (raw1 unused when sides == 1)
 // smooth/grad: [npairs*sides][H][W]
+// NAIVE = the reference built with SSE=OFF: boxNaive (sum/9) and sobelNaive (C integer division,
+// no lane duplication), both over output positions W+1 .. (H-1)*W (filter.hpp:157-223).
+template <bool NAIVE>
 __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
     uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
@@ -72,12 +79,13 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   const int ys = (blockIdx.y * PP_TY + ty) * PP_ROWS;
   if (x0 >= W || ys >= H) return;
 
-  // last row the box filter writes: rows come in pairs from y=1 while y < H-3 (filter.hpp:307)
-  const int box_last = (H & 1) ? H - 3 : H - 4;
+  // last row the box filter writes: rows come in pairs from y=1 while y < H-3 (filter.hpp:307);
+  // boxNaive writes up to row H-2, which clearBoundary then zeroes
+  const int box_last = NAIVE ? H - 3 : ((H & 1) ? H - 3 : H - 4);
 
   PreRow rows[3];
-  pre_load_row(raw, n, W, H, ys - 1, x0, rows[0]);
-  pre_load_row(raw, n, W, H, ys, x0, rows[1]);
+  pre_load_row<NAIVE>(raw, n, W, H, ys - 1, x0, rows[0]);
+  pre_load_row<NAIVE>(raw, n, W, H, ys, x0, rows[1]);
 #pragma unroll
   for (int i = 0; i < PP_ROWS; ++i) {
     const int y = ys + i;
@@ -85,14 +93,14 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     PreRow& up = rows[i % 3];
     PreRow& mid = rows[(i + 1) % 3];
     PreRow& dn = rows[(i + 2) % 3];
-    pre_load_row(raw, n, W, H, y + 1, x0, dn);
+    pre_load_row<NAIVE>(raw, n, W, H, y + 1, x0, dn);
 
     // ---- box + clearBoundary
     uint32_t s_lo = 0, s_hi = 0;
     if (y >= 1 && y <= box_last) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        int v = third(up.h[j] + mid.h[j] + dn.h[j]);
+        int v = NAIVE ? (up.h[j] + mid.h[j] + dn.h[j]) / 9 : third(up.h[j] + mid.h[j] + dn.h[j]);
         const int x = x0 + j;
         if (x < 2 || x == W - 1) v = 0;  // columns 0,1 and W-1 (buffer.hpp:637-652)
         if (j < 4) s_lo |= (uint32_t)v << (8 * j);
@@ -101,9 +109,26 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     }
     *reinterpret_cast<uint2*>(sm + (long)y * W + x0) = make_uint2(s_lo, s_hi);
 
-    // ---- sobel: decisions at x0..x0+3, each shown twice (filter.hpp:504-507)
+    // ---- sobel
     uint32_t g_lo = 0, g_hi = 0;
-    if (y >= 1 && y <= H - 4) {
+    if (NAIVE) {
+      // sobelNaive: every pixel decides for itself; positions W+1 .. (H-1)*W
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long o = (long)y * W + x0 + j;
+        if (o >= W + 1 && o <= (long)(H - 1) * W) {
+          const int p11 = up.a[j], p12 = up.a[j + 1], p13 = up.a[j + 2];
+          const int p21 = mid.a[j], p23 = mid.a[j + 2];
+          const int p31 = dn.a[j], p32 = dn.a[j + 1], p33 = dn.a[j + 2];
+          const int sx = (p11 + p31 + 2 * p21 - p13 - 2 * p23 - p33) / 9;
+          const int sy = (p11 + p13 + 2 * p12 - p31 - 2 * p32 - p33) / 9;
+          const uint32_t e = (sx * sx + sy * sy > thr_sq) ? 0xFFu : 0u;
+          if (j < 4) g_lo |= e << (8 * j);
+          else g_hi |= e << (8 * (j - 4));
+        }
+      }
+    } else if (y >= 1 && y <= H - 4) {
+      // decisions at x0..x0+3, each shown twice (filter.hpp:504-507)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int l0 = up.a[j], c0 = up.a[j + 1], r0 = up.a[j + 2];

@@ -187,6 +187,70 @@ void gpc_oracle_hash(const uint8_t* smooth, const uint8_t* grad, uint32_t* codes
 }
 
 /* ------------------------------------------------------------------ */
+/* The -DSSE=OFF build: boxNaive / sobelNaive / gpcFilter(Tau)Naive     */
+/* lib/gpc/filter.hpp:157-282                                          */
+/* ------------------------------------------------------------------ */
+
+/* Both naive filters walk nine pointers linearly over the image: output position o takes the
+ * 3x3 window centred on o in LINEAR addressing, for o = W+1 .. (H-1)*W (filter.hpp:175-186,
+ * 213-221).  The last windows reach two bytes past the buffer (read as 0 here). */
+static inline int lin_px2(const uint8_t* in, long k, long n) { return (k < 0 || k >= n) ? 0 : in[k]; }
+
+void gpc_oracle_box_naive(const uint8_t* in, uint8_t* out, int W, int H) {
+  const long n = (long)W * H;
+  for (long o = W + 1; o <= (long)(H - 1) * W; ++o) {
+    int s = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) s += lin_px2(in, o + (long)dy * W + dx, n);
+    out[o] = (uint8_t)(s / 9); /* :218 */
+  }
+}
+
+void gpc_oracle_sobel_naive(const uint8_t* in, uint8_t* grad, int W, int H, int thr) {
+  const long n = (long)W * H;
+  const int thr_sq = thr * thr; /* plain int (:159), no 16-bit wrap */
+  for (long o = W + 1; o <= (long)(H - 1) * W; ++o) {
+    const int p11 = lin_px2(in, o - W - 1, n), p12 = lin_px2(in, o - W, n), p13 = lin_px2(in, o - W + 1, n);
+    const int p21 = lin_px2(in, o - 1, n), p23 = lin_px2(in, o + 1, n);
+    const int p31 = lin_px2(in, o + W - 1, n), p32 = lin_px2(in, o + W, n), p33 = lin_px2(in, o + W + 1, n);
+    const int sx = (p11 + p31 + 2 * p21 - p13 - 2 * p23 - p33) / 9; /* C division truncates (:179) */
+    const int sy = (p11 + p13 + 2 * p12 - p31 - 2 * p32 - p33) / 9;
+    grad[o] = (sx * sx + sy * sy > thr_sq) ? 255 : 0;
+  }
+}
+
+void gpc_oracle_hash_naive(const uint8_t* smooth, const int32_t* mask, int n, uint32_t* codes,
+                           const gpc_oracle_forest* f, int W, int H) {
+  const long npx = (long)W * H;
+  for (int i = 0; i < n; ++i) {
+    const long k = mask[i];
+    uint32_t code = 0;
+    for (int t = 0; t < f->num_tests; ++t) { /* MSB first (:245-249) */
+      const int a = (int)tap(smooth, k + f->offs[2 * t], npx);
+      const int b = (int)tap(smooth, k + f->offs[2 * t + 1], npx);
+      code <<= 1;
+      if (f->type != 0 ? (a > b - f->tau[t]) : (a > b)) code |= 1u; /* plain int compare (:276) */
+    }
+    codes[k] = code;
+  }
+}
+
+int gpc_oracle_preprocess_naive(const uint8_t* raw, int W, int H, int thr,
+                                uint8_t* smooth, uint8_t* grad, int32_t* mask) {
+  size_t n = (size_t)W * H;
+  memset(smooth, 0, n);
+  memset(grad, 0, n);
+  gpc_oracle_box_naive(raw, smooth, W, H);
+  gpc_oracle_clear_boundary(smooth, W, H);
+  gpc_oracle_sobel_naive(raw, grad, W, H, thr);
+  int32_t* idx = (int32_t*)malloc(n * sizeof(int32_t));
+  int m = gpc_oracle_arr2ind(grad, (int)n, idx);
+  int k = gpc_oracle_margin(idx, m, W, H, mask);
+  free(idx);
+  return k;
+}
+
+/* ------------------------------------------------------------------ */
 /* readForest -- lib/gpc/inference.hpp:404-446                         */
 /* ------------------------------------------------------------------ */
 
@@ -478,9 +542,14 @@ int gpc_oracle_match_pair(const uint8_t* rawL, const uint8_t* rawR, int W, int H
   int cnt[2];
   for (int im = 0; im < 2; ++im) {
     mask[im] = (int32_t*)malloc(n * sizeof(int32_t));
-    cnt[im] = gpc_oracle_preprocess(raw[im], W, H, s->gradient_threshold, smooth, grad, mask[im]);
     memset(codes, 0, n * sizeof(uint32_t)); /* Buffer<uint32_t>(rows, cols, 0) :274 */
-    gpc_oracle_hash(smooth, grad, codes, f, W, H);
+    if (s->naive) {
+      cnt[im] = gpc_oracle_preprocess_naive(raw[im], W, H, s->gradient_threshold, smooth, grad, mask[im]);
+      gpc_oracle_hash_naive(smooth, mask[im], cnt[im], codes, f, W, H);
+    } else {
+      cnt[im] = gpc_oracle_preprocess(raw[im], W, H, s->gradient_threshold, smooth, grad, mask[im]);
+      gpc_oracle_hash(smooth, grad, codes, f, W, H);
+    }
     state[im] = (uint64_t*)malloc((size_t)(cnt[im] + 1) * sizeof(uint64_t));
     gpc_oracle_descriptors(codes, mask[im], cnt[im], W, s->epipolar_mode, state[im]);
   }

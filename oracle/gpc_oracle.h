@@ -50,6 +50,8 @@ typedef struct {
   int32_t vertical_tolerance;
   int32_t epipolar_mode;
   int32_t use_hashtable; /* 0: sort-match (findCorrespondences), 1: ndb::Hashmatch */
+  int32_t naive;         /* 0: the reference built with -D_INTRINSICS_SSE (default, parity target);
+                            1: the reference built with SSE=OFF (*Naive kernels, filter.hpp:157-282) */
 } gpc_oracle_settings;
 
 /* synthetic inputs, SURVEY.md 8(d) */
@@ -65,6 +67,15 @@ int gpc_oracle_arr2ind(const uint8_t* a, int n, int32_t* ind);
 int gpc_oracle_margin(const int32_t* idx, int m, int W, int H, int32_t* out);
 void gpc_oracle_hash(const uint8_t* smooth, const uint8_t* grad, uint32_t* codes,
                      const gpc_oracle_forest* f, int W, int H);
+
+/* filter.hpp *Naive kernels (the reference's -DSSE=OFF build) */
+void gpc_oracle_box_naive(const uint8_t* in, uint8_t* out, int W, int H);
+void gpc_oracle_sobel_naive(const uint8_t* in, uint8_t* grad, int W, int H, int thr);
+/* codes only at mask positions (gpcFilterNaive / gpcFilterTauNaive walk idx) */
+void gpc_oracle_hash_naive(const uint8_t* smooth, const int32_t* mask, int n, uint32_t* codes,
+                           const gpc_oracle_forest* f, int W, int H);
+int gpc_oracle_preprocess_naive(const uint8_t* raw, int W, int H, int thr,
+                                uint8_t* smooth, uint8_t* grad, int32_t* mask);
 
 /* inference.hpp */
 int gpc_oracle_parse_forest_text(const char* text, int W, int H, gpc_oracle_forest* f);

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libgpc_oracle.so")
 ORACLE_FAST_SO = os.path.join(HERE, "libgpc_oracle_fast.so")
 REF_SO = os.path.join(HERE, "_ref", "libgpc_ref.so")
+REF_NAIVE_SO = os.path.join(HERE, "_ref", "libgpc_ref_naive.so")
 MAX_TESTS = 32
 
 
@@ -37,6 +38,7 @@ class Settings(C.Structure):
         ("vertical_tolerance", C.c_int32),
         ("epipolar_mode", C.c_int32),
         ("use_hashtable", C.c_int32),
+        ("naive", C.c_int32),
     ]
 
 
@@ -80,6 +82,7 @@ class Oracle:
         L.gpc_oracle_parse_forest_text.restype = C.c_int
         L.gpc_oracle_read_forest.restype = C.c_int
         L.gpc_oracle_preprocess.restype = C.c_int
+        L.gpc_oracle_preprocess_naive.restype = C.c_int
         L.gpc_oracle_find_correspondences.restype = C.c_int
         L.gpc_oracle_hash_correspondences.restype = C.c_int
         L.gpc_oracle_rectified_filter.restype = C.c_int
@@ -127,6 +130,35 @@ class Oracle:
         grad = np.empty((H, W), np.uint8)
         mask = np.empty(H * W, np.int32)
         n = self.lib.gpc_oracle_preprocess(_u8p(raw), W, H, int(thr), _u8p(smooth), _u8p(grad), _i32p(mask))
+        return smooth, grad, mask[:n].copy()
+
+    # ---- the -DSSE=OFF build (*Naive kernels)
+    def box_naive(self, raw):
+        H, W = raw.shape
+        out = np.zeros((H, W), np.uint8)
+        self.lib.gpc_oracle_box_naive(_u8p(raw), _u8p(out), W, H)
+        return out
+
+    def sobel_naive(self, raw, thr):
+        H, W = raw.shape
+        out = np.zeros((H, W), np.uint8)
+        self.lib.gpc_oracle_sobel_naive(_u8p(raw), _u8p(out), W, H, int(thr))
+        return out
+
+    def hash_naive(self, smooth, mask, forest):
+        H, W = smooth.shape
+        codes = np.zeros((H, W), np.uint32)
+        mask = np.ascontiguousarray(mask, np.int32)
+        self.lib.gpc_oracle_hash_naive(_u8p(smooth), _i32p(mask), len(mask), _u32p(codes), C.byref(forest), W, H)
+        return codes
+
+    def preprocess_naive(self, raw, thr):
+        raw = np.ascontiguousarray(raw)
+        H, W = raw.shape
+        smooth = np.empty((H, W), np.uint8)
+        grad = np.empty((H, W), np.uint8)
+        mask = np.empty(H * W, np.int32)
+        n = self.lib.gpc_oracle_preprocess_naive(_u8p(raw), W, H, int(thr), _u8p(smooth), _u8p(grad), _i32p(mask))
         return smooth, grad, mask[:n].copy()
 
     # ---- forest
@@ -188,9 +220,9 @@ class Oracle:
         return out[:n].copy(), nl.value, nr.value
 
 
-def sparsematch_settings(thr=5, disp_high=128, vtol=0, epipolar=True, hashtable=False):
+def sparsematch_settings(thr=5, disp_high=128, vtol=0, epipolar=True, hashtable=False, naive=False):
     """Settings of samples/sparsematch.cpp:29-34."""
-    return Settings(thr, disp_high, vtol, int(epipolar), int(hashtable))
+    return Settings(thr, disp_high, vtol, int(epipolar), int(hashtable), int(naive))
 
 
 def supports_fnv(oracle, supp):
@@ -205,18 +237,19 @@ def supports_fnv(oracle, supp):
 class Ref:
     """The reference's own SSE kernels (filter.hpp), when oracle/_ref is built."""
 
-    def __init__(self):
-        if not os.path.exists(REF_SO):
-            raise FileNotFoundError(REF_SO)
-        self.lib = L = C.CDLL(REF_SO)
+    def __init__(self, naive=False):
+        path = REF_NAIVE_SO if naive else REF_SO
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = C.CDLL(path)
         L.gpc_ref_arr2ind.restype = C.c_int
         L.gpc_ref_is_sse.restype = C.c_int
         L.gpc_ref_cpu_baseline_pair.restype = C.c_int
         L.gpc_ref_hashmatch.restype = C.c_int
 
     @staticmethod
-    def available():
-        return os.path.exists(REF_SO)
+    def available(naive=False):
+        return os.path.exists(REF_NAIVE_SO if naive else REF_SO)
 
     @staticmethod
     def _padded(img, front=64, back=64):
@@ -248,6 +281,19 @@ class Ref:
         ind = np.empty(grad.size + 64, np.int32)
         m = self.lib.gpc_ref_arr2ind(_u8p(src), grad.size, _i32p(ind))
         return ind[:m].copy()
+
+    def hash_idx(self, smooth, grad, forest, idx):
+        """gpcFilter/gpcFilterTau with the index list the non-SSE build walks (filter.hpp:237-281)."""
+        H, W = smooth.shape
+        keep1, s = self._padded(smooth, front=64 + 16 * W, back=64 + 16 * W)
+        keep2, g = self._padded(grad)
+        codes = np.zeros((H, W), np.uint32)
+        offs = np.array(forest.offs[: 2 * forest.num_tests], np.int32)
+        tau = np.array(forest.tau[: max(forest.num_tests, 1)], np.int32)
+        idx = np.ascontiguousarray(idx, np.int32)
+        self.lib.gpc_ref_hash_idx(_u8p(s), _u8p(g), _u32p(codes), _i32p(offs), _i32p(tau), forest.num_tests,
+                                  forest.type, W, H, _i32p(idx), len(idx))
+        return codes
 
     def hash(self, smooth, grad, forest, nthreads=1):
         H, W = smooth.shape

@@ -90,6 +90,19 @@ int gpc_ref_hashmatch(const uint64_t* ss, const int32_t* sk, int ns, const uint6
   return (int)corr.size();
 }
 
+// same, with the candidate index list (only the -DSSE=OFF build reads it)
+void gpc_ref_hash_idx(const uint8_t* smooth, const uint8_t* grad, uint32_t* codes, const int32_t* offs,
+                      const int32_t* tau, int ntests, int type, int w, int h, const int32_t* idx, int nidx) {
+  std::vector<int32_t> mask(offs, offs + 2 * ntests);
+  std::vector<int> ix(idx, idx + nidx);
+  if (type == 0) {
+    ndb::gpcFilter(const_cast<uint8_t*>(smooth), grad, codes, mask, ix, w, h, 1);
+  } else {
+    std::vector<int> t(tau, tau + ntests);
+    ndb::gpcFilterTau(const_cast<uint8_t*>(smooth), grad, codes, mask, t, ix, w, h, 1);
+  }
+}
+
 int gpc_ref_is_sse(void) {
 #ifdef _INTRINSICS_SSE
   return 1;

@@ -34,6 +34,9 @@ int main(int argc, char** argv) {
     std::cout << "Left image : " << leftPath << std::endl;
     std::cout << "Right image: " << rightPath << std::endl;
   }
+#ifdef _INTRINSICS_SSE
+  std::cout << "Using SSE intrinsics" << std::endl;  // arithmetic of the reference's default build
+#endif
   std::cout << "Using HIP kernels (gfx950)" << std::endl;
 
   typedef gpc::inference::Forest Forest;

@@ -15,9 +15,11 @@ REF_SAMPLE = "/root/reference/samples/sparsematch.cpp"
 REF_ON_AMD = os.path.join(ROOT, "oracle", "_ref", "ref_sparsematch_on_amd_headers")
 
 
-def compile_cpp(src, out):
+def compile_cpp(src, out, sse=True):
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+    # -D_INTRINSICS_SSE is the reference's default build option (samples/CMakeLists.txt:13-17)
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + (["-D_INTRINSICS_SSE"] if sse else []) +
+                          ["-I" + os.path.join(ROOT, "include"), "-o", out, src,
                            "-L" + LIBDIR, "-lgpc_hip", "-lz", "-lpthread",
                            "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
     return out
