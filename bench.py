@@ -36,6 +36,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="contexts (HIP streams + workspaces) the steps alternate over; 1 = strictly serial steps "
+                         "(default: clean per-kernel timing); 2 lets step k+1's HBM-bound kernels overlap step k's "
+                         "LDS/VALU-bound ones (+9 % throughput, reported as `two_stream_pipeline` at N=1 anyway)")
     return ap.parse_args()
 
 
@@ -97,12 +101,18 @@ def main():
     from opengpc_amd.synth import synth_batch
 
     W, H, B = args.width, args.height, args.batch
-    ctx = g.Context(local_rank)
-    fm = ctx.load_forest(args.forest, W, H)
+    P = max(1, args.pipeline)
     settings = g.Settings.sparsematch()
-    stream = torch.cuda.Stream(device=dev)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.reserve(W, H, B)
+    ctxs, streams = [], []
+    for _ in range(P):  # one context = one HIP stream + one set of workspaces
+        c = g.Context(local_rank)
+        fm = c.load_forest(args.forest, W, H)
+        st = torch.cuda.Stream(device=dev)
+        c.set_stream(st.cuda_stream)
+        c.reserve(W, H, B)
+        ctxs.append(c)
+        streams.append(st)
+    ctx = ctxs[0]
 
     # pair i -> rank i mod N  (weak scaling: B pairs per GPU per step)
     indices = gdist.shard_indices(rank, world, B)
@@ -110,27 +120,50 @@ def main():
     d_L = torch.from_numpy(Lh).to(dev)
     d_R = torch.from_numpy(Rh).to(dev)
     cap = (W - 26) * (H - 26)  # a row can emit at most W-26 supports
-    d_out = torch.empty((B, cap, 3), dtype=torch.int32, device=dev)  # gpc_support = 12 bytes
-    d_counts = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_ncand = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    # every in-flight step owns its outputs (gpc_support = 12 bytes)
+    d_outs = [torch.empty((B, cap, 3), dtype=torch.int32, device=dev) for _ in range(P)]
+    d_cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(P)]
+    d_ncs = [torch.zeros((B, 2), dtype=torch.int32, device=dev) for _ in range(P)]
+    d_out, d_counts, d_ncand = d_outs[0], d_cnts[0], d_ncs[0]
     torch.cuda.synchronize(dev)
 
+    step_no = [0]
+
     def step():
-        ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, d_out.data_ptr(), cap,
-                               d_counts.data_ptr(), d_ncand.data_ptr())
+        i = step_no[0] % P
+        step_no[0] += 1
+        ctxs[i].match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, d_outs[i].data_ptr(), cap,
+                                   d_cnts[i].data_ptr(), d_ncs[i].data_ptr())
 
     def device_sync():
-        ctx.synchronize()  # the stream the kernels run on
+        for c in ctxs:
+            c.synchronize()  # the streams the kernels run on
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, P)):
         step()
     device_sync()
 
-    # HIP events around every launch of the pipeline's kernels, on the stream they run on
+    # HIP events around every launch of the dominant kernel, on the stream it runs on; the other
+    # kernels are bracketed in a separate pass below so their event records do not sit in the
+    # timed region
+    for c in ctxs:
+        c.enable_kernel_timing(True, only=[DOMINANT_KERNEL])
+        c.reset_kernel_timing()
+    step_no[0] = 0
+    elapsed = gdist.timed_steps(step, args.steps, device_sync)
+    dom_ms, dom_n = 0.0, 0
+    for c in ctxs:
+        ms, n = c.kernel_times()[DOMINANT_KERNEL]
+        dom_ms += ms
+        dom_n += n
+        c.enable_kernel_timing(False)
+    # per-kernel split: a few extra, serial steps with every kernel bracketed (not part of `value`)
     ctx.enable_kernel_timing(True)
     ctx.reset_kernel_timing()
-    elapsed = gdist.timed_steps(step, args.steps, device_sync)
+    for _ in range(5):
+        ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, d_out.data_ptr(), cap,
+                               d_counts.data_ptr(), d_ncand.data_ptr())
     ktimes = ctx.kernel_times()
     ctx.enable_kernel_timing(False)
 
@@ -177,12 +210,8 @@ def main():
                 kinfo[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": n}
                 if name in alg:
                     kinfo[name]["alg_GBs"] = round(alg[name] / (ms / n * 1e-3) / 1e9, 1)
-        dom_ms, dom_n = ktimes.get(DOMINANT_KERNEL, (0.0, 0))
         dom_name = DOMINANT_KERNEL
-        # the dominant kernel is whichever has the largest summed time
-        for name, (ms, n) in ktimes.items():
-            if n and ms > dom_ms:
-                dom_name, dom_ms, dom_n = name, ms, n
+        serial_dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
         achieved = alg.get(dom_name, 0.0) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -205,6 +234,10 @@ def main():
             "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),
             "pipeline_alg_bytes_per_pair": a_pair,
             "pipeline_frac": round(a_pair * pairs_per_step * args.steps / t_max / 1e9 / HBM_PEAK_GBS, 4),
+            "launches_timed": dom_n,
+            "note": "duration = HIP events around every %s launch inside the timed region (steps of %d "
+                    "alternating streams may overlap it with the next step's HBM-bound kernels); `kernels` = "
+                    "per-kernel split of 5 extra serial steps; largest there: %s" % (dom_name, P, serial_dom),
             "kernels": kinfo,
         }
 
@@ -212,13 +245,44 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, W, H)
 
+        # the same steps alternating over TWO streams/workspaces (step k+1 overlaps step k); reported
+        # beside the serial headline because its per-kernel event times are no longer clean
+        two = None
+        if world == 1 and P == 1:
+            c2 = g.Context(local_rank)
+            c2.load_forest(args.forest, W, H)
+            st2 = torch.cuda.Stream(device=dev)
+            c2.set_stream(st2.cuda_stream)
+            c2.reserve(W, H, B)
+            o2 = torch.empty((B, cap, 3), dtype=torch.int32, device=dev)
+            n2 = torch.zeros(B, dtype=torch.int32, device=dev)
+            m2 = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+            pair = [(ctx, d_out, d_counts, d_ncand), (c2, o2, n2, m2)]
+
+            def step2(i):
+                c, o, n, m = pair[i & 1]
+                c.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, o.data_ptr(), cap,
+                                     n.data_ptr(), m.data_ptr())
+            for i in range(4):
+                step2(i)
+            device_sync(); c2.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                step2(i)
+            device_sync(); c2.synchronize()
+            dt2 = (time.perf_counter() - t2) / args.steps
+            same = bool(torch.equal(n2, d_counts) and torch.equal(o2[0, : int(counts[0])], d_out[0, : int(counts[0])]))
+            two = {"streams": 2, "ms_per_step": round(dt2 * 1e3, 4), "value": round(mpix_per_step / dt2, 1),
+                   "unit": "Mpix/s", "identical_outputs": same}
+            c2.close()
+
         # BASELINE configs[1] taken literally: ONE pair per step (launch/occupancy-bound, reported
         # beside the batched headline, never instead of it)
         single = None
         if world == 1:
             def step1():
-                ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, 1, settings, d_out.data_ptr(), cap,
-                                       d_counts.data_ptr(), d_ncand.data_ptr())
+                ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, 1, settings, d_outs[-1].data_ptr(), cap,
+                                       d_cnts[-1].data_ptr(), d_ncs[-1].data_ptr())
             for _ in range(5):
                 step1()
             device_sync()
@@ -249,7 +313,7 @@ def main():
                             "in batches of %d pairs per GPU per step (configs[3] sharding: pair i -> GPU i mod N)"
                             % (W, H, os.path.basename(args.forest), B),
                 "width": W, "height": H, "pairs_per_gpu_per_step": B, "tests": fm.num_tests,
-                "forest_type": fm.type, "parallelism": "pairs-dp%d" % world,
+                "forest_type": fm.type, "parallelism": "pairs-dp%d" % world, "streams_per_gpu": P,
                 "timed_region": "raw pairs in HBM -> supports in HBM (no PCIe)",
             },
             "pairs_per_s": round(pairs_per_step * args.steps / t_max, 1),
@@ -259,12 +323,14 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "single_pair": single,
+            "two_stream_pipeline": two,
         }
         if cpu:
             line["speedup_vs_cpu_1thread"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     gdist.finalize()
 
 

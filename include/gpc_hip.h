@@ -166,6 +166,9 @@ int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* ra
  * the named kernels is bracketed by hipEvents; gpc_hip_kernel_time returns the summed
  * milliseconds and launch count since the last reset (synchronises the stream). */
 int gpc_hip_enable_kernel_timing(gpc_hip_ctx* ctx, int enable);
+/* Restrict the bracketing to the kernels whose index bit is set (default: all).  Every pair of
+ * event records costs a little stream time, so a benchmark times only the kernel it reports. */
+int gpc_hip_set_kernel_timing_mask(gpc_hip_ctx* ctx, unsigned mask);
 int gpc_hip_reset_kernel_timing(gpc_hip_ctx* ctx);
 int gpc_hip_kernel_count(void);
 const char* gpc_hip_kernel_name(int index);

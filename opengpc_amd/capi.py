@@ -70,7 +70,7 @@ SYMBOLS = [
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
-    "gpc_hip_enable_kernel_timing", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
+    "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_time",
 ]
 
@@ -115,6 +115,7 @@ def load():
     L.gpc_hip_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    L.gpc_hip_set_kernel_timing_mask.argtypes = [C.c_void_p, C.c_uint]
     L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]
     L.gpc_hip_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _lib = L
@@ -285,7 +286,15 @@ class Context:
                                                    C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
 
     # ---- measurement
-    def enable_kernel_timing(self, on=True):
+    def enable_kernel_timing(self, on=True, only=None):
+        """HIP-event bracketing of kernel launches; `only` = iterable of kernel names to restrict it to."""
+        mask = 0xFFFFFFFF
+        if only is not None:
+            names = [self.L.gpc_hip_kernel_name(i).decode() for i in range(self.L.gpc_hip_kernel_count())]
+            mask = 0
+            for n in only:
+                mask |= 1 << names.index(n)
+        self._ck(self.L.gpc_hip_set_kernel_timing_mask(self.h, mask))
         self._ck(self.L.gpc_hip_enable_kernel_timing(self.h, int(on)))
 
     def reset_kernel_timing(self):

@@ -71,6 +71,7 @@ struct gpc_hip_ctx {
 
   // timing
   bool timing = false;
+  unsigned timing_mask = 0xFFFFFFFFu;  // which KernelIds are bracketed by events when timing is on
   std::vector<TimedSpan> spans;
   std::vector<TimedSpan> free_spans;
 };
@@ -117,7 +118,7 @@ struct Timed {
   gpc_hip_ctx* c;
   TimedSpan s;
   bool on;
-  Timed(gpc_hip_ctx* ctx, int kid) : c(ctx), on(ctx->timing) {
+  Timed(gpc_hip_ctx* ctx, int kid) : c(ctx), on(ctx->timing && ((ctx->timing_mask >> kid) & 1u)) {
     if (!on) return;
     if (!c->free_spans.empty()) {
       s = c->free_spans.back();
@@ -256,7 +257,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
                     // S >= NT*SPT because the rank phase reuses the accumulators as bucket counters
     while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < jnt * jspt) ++log2s;
-    const size_t join_lds = (size_t)12 * ((1u << log2s) + 1);
+    const size_t join_lds = ((size_t)12 * ((1u << log2s) + 1) + 15) / 16 * 16;
     const bool use_join = c->row_kernel == 0 && jspt * jnt >= W && join_lds <= 150 * 1024;
     const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
     const bool use_bucket = c->row_kernel == 1 && spt <= 16;
@@ -883,6 +884,12 @@ extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
 int gpc_hip_enable_kernel_timing(gpc_hip_ctx* c, int enable) {
   if (!c) return GPC_E_INVALID;
   c->timing = enable != 0;
+  return GPC_OK;
+}
+
+int gpc_hip_set_kernel_timing_mask(gpc_hip_ctx* c, unsigned mask) {
+  if (!c) return GPC_E_INVALID;
+  c->timing_mask = mask;
   return GPC_OK;
 }
 

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(NT) void k_row_join(
       cl[j] = (x < W) ? rowl[x] : RJ_EMPTY;
       cr[j] = (x < W) ? rowr[x] : RJ_EMPTY;
     }
-    for (int i = tid; i < 3 * (S + 1); i += NT) rj_lds[i] = 0u;
+    {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
+      uint4* z = reinterpret_cast<uint4*>(rj_lds);
+      for (int i = tid; i < (3 * (S + 1) + 3) / 4; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid == 0) {
       s_max_r = -1;
       s_tail_cnt = 0;
