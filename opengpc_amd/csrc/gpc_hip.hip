@@ -190,7 +190,7 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
   // threshold^2 passes through _mm_set1_epi16 in the SSE build (filter.hpp:418); sobelNaive keeps the int (:159)
   const int thr_sq = c->naive ? (thr & 0xFF) * (thr & 0xFF) : (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
-  dim3 grid((W / 8 + PP_TX - 1) / PP_TX, (H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS), nimg);
+  dim3 grid((W / PP_PX + PP_TX - 1) / PP_TX, (H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS), nimg);
   Timed t(c, KID_PREPROCESS);
   if (c->naive)
     hipLaunchKernelGGL(gpc::k_preprocess<true>, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,

@@ -3,16 +3,19 @@
 // Replaces ndb::box (filter.hpp:293-392), Buffer::clearBoundary (buffer.hpp:630-654) and
 // ndb::sobel (filter.hpp:404-519) as called by Forest::preprocessImage (inference.hpp:306-313).
 //
-// HBM-bound streaming kernel: 1 byte read, 2 bytes written per pixel.  One thread owns an
-// 8-pixel-wide column strip (one aligned 8-byte load per row, 8-byte stores) and marches
+// HBM-bound streaming kernel: 1 byte read, 2 bytes written per pixel.  One thread owns a
+// PP_PX (8)-pixel-wide column strip (one aligned 8-byte load per row, 8-byte stores) and marches
 // down PP_ROWS rows with a rolling 3-row window in registers, so every raw row is read
-// (PP_ROWS+2)/PP_ROWS times.  The 8-pixel strip is also the natural unit of the
-// reference's Sobel lane-duplication quirk (4 decisions shown twice per 8 pixels).
+// (PP_ROWS+2)/PP_ROWS times.  An 8-pixel group is the natural unit of the reference's Sobel
+// lane-duplication quirk (4 decisions shown twice per 8 pixels).
 #pragma once
 #include "gpc_device.h"
 
+#ifndef PP_PX
+#define PP_PX 8        // pixels per thread along x (8 or 16); measured on MI355X: 8 -> 29.5 us, 16 -> 32.1 us per 64 images
+#endif
 #define PP_ROWS 8      // rows per thread
-#define PP_TX 64       // threads along x per block (64 strips = 512 pixels)
+#define PP_TX 64       // threads along x per block
 #define PP_TY 4        // row strips per block
 
 namespace gpc {
@@ -21,8 +24,8 @@ __device__ __forceinline__ int third(int s) { return (s * 21846) >> 16; }  // mu
 __device__ __forceinline__ int ninth(int s) { return (s * 7282) >> 16; }   // mulhi_epi16(s,7282)
 
 struct PreRow {
-  int h[8];   // SSE: third(p[x-1]+p[x]+p[x+1]) for the 8 strip pixels; NAIVE: the plain 3-sum
-  int a[10];  // raw pixels x0-1 .. x0+8 (SSE needs the first 6: 4 Sobel decisions per strip)
+  int h[PP_PX];      // SSE: third(p[x-1]+p[x]+p[x+1]) for the strip's pixels; NAIVE: the plain 3-sum
+  int a[PP_PX + 2];  // raw pixels x0-1 .. x0+PP_PX
 };
 
 // Linear addressing as in the reference: the byte left of column 0 is the previous row's
@@ -30,28 +33,32 @@ struct PreRow {
 template <bool NAIVE>
 __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, long n, int W, int H,
                                              int r, int x0, PreRow& o) {
-  int p[10];
+  int p[PP_PX + 2];
   if (r < 0 || r >= H) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) p[i] = 0;
+    for (int i = 0; i < PP_PX + 2; ++i) p[i] = 0;
     // linear addressing: the byte "left of" column 0 of the row below the image is the image's
     // last byte (the naive filters' window at position (H-1)*W reaches it)
     if (r == H && x0 == 0) p[0] = raw[n - 1];
   } else {
     long k = (long)r * W + x0;
-    uint2 v = *reinterpret_cast<const uint2*>(raw + k);
-    p[0] = (k - 1 >= 0) ? raw[k - 1] : 0;
-    p[9] = (k + 8 < n) ? raw[k + 8] : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      p[1 + i] = (v.x >> (8 * i)) & 0xFF;
-      p[5 + i] = (v.y >> (8 * i)) & 0xFF;
+    uint32_t w[PP_PX / 4];
+    if (PP_PX == 16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(raw + k);
+      w[0] = v.x; w[1] = v.y; w[PP_PX / 4 - 2] = v.z; w[PP_PX / 4 - 1] = v.w;
+    } else {
+      const uint2 v = *reinterpret_cast<const uint2*>(raw + k);
+      w[0] = v.x; w[1] = v.y;
     }
+    p[0] = (k - 1 >= 0) ? raw[k - 1] : 0;
+    p[PP_PX + 1] = (k + PP_PX < n) ? raw[k + PP_PX] : 0;
+#pragma unroll
+    for (int i = 0; i < PP_PX; ++i) p[1 + i] = (w[i / 4] >> (8 * (i % 4))) & 0xFF;
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
+  for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) o.a[i] = p[i];
+  for (int i = 0; i < PP_PX + 2; ++i) o.a[i] = p[i];
 }
 
 // raw0/raw1: [npairs][H][W] for side 0 / 1 (raw1 unused when sides == 1)
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   }
 
   const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;
-  const int x0 = (blockIdx.x * PP_TX + tx) * 8;
+  const int x0 = (blockIdx.x * PP_TX + tx) * PP_PX;
   const int ys = (blockIdx.y * PP_TY + ty) * PP_ROWS;
   if (x0 >= W || ys >= H) return;
 
@@ -96,25 +103,31 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     pre_load_row<NAIVE>(raw, n, W, H, y + 1, x0, dn);
 
     // ---- box + clearBoundary
-    uint32_t s_lo = 0, s_hi = 0;
+    uint32_t sw[PP_PX / 4];
+#pragma unroll
+    for (int q = 0; q < PP_PX / 4; ++q) sw[q] = 0;
     if (y >= 1 && y <= box_last) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < PP_PX; ++j) {
         int v = NAIVE ? (up.h[j] + mid.h[j] + dn.h[j]) / 9 : third(up.h[j] + mid.h[j] + dn.h[j]);
         const int x = x0 + j;
         if (x < 2 || x == W - 1) v = 0;  // columns 0,1 and W-1 (buffer.hpp:637-652)
-        if (j < 4) s_lo |= (uint32_t)v << (8 * j);
-        else s_hi |= (uint32_t)v << (8 * (j - 4));
+        sw[j / 4] |= (uint32_t)v << (8 * (j % 4));
       }
     }
-    *reinterpret_cast<uint2*>(sm + (long)y * W + x0) = make_uint2(s_lo, s_hi);
+    if (PP_PX == 16)
+      *reinterpret_cast<uint4*>(sm + (long)y * W + x0) = make_uint4(sw[0], sw[1], sw[PP_PX / 4 - 2], sw[PP_PX / 4 - 1]);
+    else
+      *reinterpret_cast<uint2*>(sm + (long)y * W + x0) = make_uint2(sw[0], sw[1]);
 
     // ---- sobel
-    uint32_t g_lo = 0, g_hi = 0;
+    uint32_t gw[PP_PX / 4];
+#pragma unroll
+    for (int q = 0; q < PP_PX / 4; ++q) gw[q] = 0;
     if (NAIVE) {
       // sobelNaive: every pixel decides for itself; positions W+1 .. (H-1)*W
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < PP_PX; ++j) {
         const long o = (long)y * W + x0 + j;
         if (o >= W + 1 && o <= (long)(H - 1) * W) {
           const int p11 = up.a[j], p12 = up.a[j + 1], p13 = up.a[j + 2];
@@ -123,25 +136,30 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
           const int sx = (p11 + p31 + 2 * p21 - p13 - 2 * p23 - p33) / 9;
           const int sy = (p11 + p13 + 2 * p12 - p31 - 2 * p32 - p33) / 9;
           const uint32_t e = (sx * sx + sy * sy > thr_sq) ? 0xFFu : 0u;
-          if (j < 4) g_lo |= e << (8 * j);
-          else g_hi |= e << (8 * (j - 4));
+          gw[j / 4] |= e << (8 * (j % 4));
         }
       }
     } else if (y >= 1 && y <= H - 4) {
-      // decisions at x0..x0+3, each shown twice (filter.hpp:504-507)
+      // per 8-pixel group: decisions at its first 4 pixels, each shown twice (filter.hpp:504-507)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int l0 = up.a[j], c0 = up.a[j + 1], r0 = up.a[j + 2];
-        const int l1 = mid.a[j], r1 = mid.a[j + 2];
-        const int l2 = dn.a[j], c2 = dn.a[j + 1], r2 = dn.a[j + 2];
-        const int gx = ninth(l0 + l2 + 2 * l1) - ninth(r0 + r2 + 2 * r1);
-        const int gy = ninth(l0 + r0 + 2 * c0) - ninth(l2 + r2 + 2 * c2);
-        const uint32_t e = (gx * gx + gy * gy > thr_sq) ? 0xFFFFu : 0u;
-        if (j < 2) g_lo |= e << (16 * j);
-        else g_hi |= e << (16 * (j - 2));
+      for (int g8 = 0; g8 < PP_PX / 8; ++g8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = g8 * 8 + j;
+          const int l0 = up.a[q], c0 = up.a[q + 1], r0 = up.a[q + 2];
+          const int l1 = mid.a[q], r1 = mid.a[q + 2];
+          const int l2 = dn.a[q], c2 = dn.a[q + 1], r2 = dn.a[q + 2];
+          const int gx = ninth(l0 + l2 + 2 * l1) - ninth(r0 + r2 + 2 * r1);
+          const int gy = ninth(l0 + r0 + 2 * c0) - ninth(l2 + r2 + 2 * c2);
+          const uint32_t e = (gx * gx + gy * gy > thr_sq) ? 0xFFFFu : 0u;
+          gw[g8 * 2 + j / 2] |= e << (16 * (j % 2));
+        }
       }
     }
-    *reinterpret_cast<uint2*>(gr + (long)y * W + x0) = make_uint2(g_lo, g_hi);
+    if (PP_PX == 16)
+      *reinterpret_cast<uint4*>(gr + (long)y * W + x0) = make_uint4(gw[0], gw[1], gw[PP_PX / 4 - 2], gw[PP_PX / 4 - 1]);
+    else
+      *reinterpret_cast<uint2*>(gr + (long)y * W + x0) = make_uint2(gw[0], gw[1]);
   }
 }
 

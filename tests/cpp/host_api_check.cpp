@@ -67,6 +67,39 @@ int main(int argc, char** argv) {
     printf("MISSING %zu %d %d %d\n", m.mask.size(), m.type, m.width, m.height);
     return 0;
   }
+  // host_api_check api <forest> <left.png> <right.png> <epipolar 0/1> <hashtable 0/1> <out.bin>
+  //   runs Forest::preprocessImage x2, stereoMatch, rectifiedMatch and matchPair on the GPU and dumps
+  //   [n_corr][corr...][n_supp][supp...][n_fused][fused...][maskL size][maskR size] as int32/float32 words
+  if (cmd == "api" && argc == 8) {
+    ndb::Buffer<uint8_t> L, R;
+    if (L.readPNG(argv[3]) || R.readPNG(argv[4])) return 3;
+    gpc::inference::Forest forest;
+    gpc::inference::InferenceSettings st = gpc::inference::InferenceSettings().builder().gradientThreshold(5)
+        .verticalTolerance(1).dispHigh(64).epipolarMode(atoi(argv[5]) != 0).useHashtable(atoi(argv[6]) != 0);
+    gpc::inference::Forest::FilterMask fm = forest.readForest(argv[2], L.cols(), L.rows());
+    gpc::inference::Forest::PreprocessedImage lp = forest.preprocessImage(L, st);
+    gpc::inference::Forest::PreprocessedImage rp = forest.preprocessImage(R, st);
+    std::vector<ndb::Correspondence> corr = forest.stereoMatch(lp, rp, fm, st);
+    std::vector<ndb::Support> supp = forest.rectifiedMatch(lp, rp, fm, st);
+    std::vector<ndb::Support> fused = forest.matchPair(L, R, fm, st);
+    FILE* f = fopen(argv[7], "wb");
+    int n = (int)corr.size();
+    fwrite(&n, 4, 1, f);
+    if (n) fwrite(corr.data(), sizeof(ndb::Correspondence), n, f);
+    n = (int)supp.size();
+    fwrite(&n, 4, 1, f);
+    if (n) fwrite(supp.data(), sizeof(ndb::Support), n, f);
+    n = (int)fused.size();
+    fwrite(&n, 4, 1, f);
+    if (n) fwrite(fused.data(), sizeof(ndb::Support), n, f);
+    n = (int)lp.mask.size();
+    fwrite(&n, 4, 1, f);
+    n = (int)rp.mask.size();
+    fwrite(&n, 4, 1, f);
+    fclose(f);
+    printf("API %zu %zu %zu\n", corr.size(), supp.size(), fused.size());
+    return 0;
+  }
   if (cmd == "forest" && argc == 5) {
     gpc::inference::Forest f;
     gpc::inference::Forest::FilterMask m = f.readForest(argv[2], atoi(argv[3]), atoi(argv[4]));

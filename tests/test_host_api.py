@@ -166,3 +166,46 @@ def test_reference_sample_runs_on_the_hip_path(tmp_path, golden, forest_paths):
     assert m, out
     assert [int(m.group(1)), int(m.group(2)), int(m.group(3))] == c["n_cand"] + [c["tau"]["epipolar"]["n"]]
     assert os.path.exists(str(tmp_path / "disparity.png"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epipolar,hashtable", [(1, 0), (0, 0), (1, 1), (0, 1)])
+@pytest.mark.parametrize("sse", [True, False], ids=["sse_build", "naive_build"])
+def test_cpp_forest_api_matches_oracle(check_bin, tmp_path, oracle, forest_paths, epipolar, hashtable, sse):
+    """gpc::inference::Forest::{preprocessImage, stereoMatch, rectifiedMatch, matchPair} through the C++
+    headers on the GPU; built with and without -D_INTRINSICS_SSE like the reference's two build modes."""
+    from oracle.pyoracle import CORR_DTYPE, SUPPORT_DTYPE, sparsematch_settings
+    binp = check_bin if sse else compile_cpp(os.path.join(ROOT, "tests", "cpp", "host_api_check.cpp"),
+                                             os.path.join(BIN, "host_api_check_naive"), sse=False)
+    W, H = 272, 61
+    L, R, lp, rp = write_pair(tmp_path, W, H, 3, 9)
+    outp = str(tmp_path / "api.bin")
+    run(binp, "api", forest_paths["tau"], lp, rp, str(epipolar), str(hashtable), outp)
+    raw = np.fromfile(outp, np.uint8)
+    pos = 0
+
+    def take(dtype):
+        nonlocal pos
+        n = int(raw[pos:pos + 4].view(np.int32)[0])
+        pos += 4
+        a = raw[pos:pos + n * dtype.itemsize].view(dtype)
+        pos += n * dtype.itemsize
+        return a
+    corr, supp, fused = take(CORR_DTYPE), take(SUPPORT_DTYPE), take(SUPPORT_DTYPE)
+    nl, nr = raw[pos:pos + 8].view(np.int32)
+    rc, f = oracle.read_forest(forest_paths["tau"], W, H)
+    s = sparsematch_settings(5, 64, 1, bool(epipolar), bool(hashtable), not sse)
+    want, wl, wr = oracle.match_pair(L, R, f, s)
+    assert (nl, nr) == (wl, wr)
+    assert np.array_equal(supp, want) and np.array_equal(fused, want)
+    # stereoMatch = the same correspondences before the disparity filter
+    pre = (oracle.preprocess if sse else oracle.preprocess_naive)
+    pl, pr = pre(L, 5), pre(R, 5)
+    if sse:
+        cl, cr = oracle.hash(pl[0], pl[1], f), oracle.hash(pr[0], pr[1], f)
+    else:
+        cl, cr = oracle.hash_naive(pl[0], pl[2], f), oracle.hash_naive(pr[0], pr[2], f)
+    sl, sr = oracle.descriptors(cl, pl[2], W, bool(epipolar)), oracle.descriptors(cr, pr[2], W, bool(epipolar))
+    fn = oracle.hash_correspondences if hashtable else oracle.find_correspondences
+    wc = fn(sl, pl[2], sr, pr[2], W)
+    assert np.array_equal(corr, wc)
