@@ -307,64 +307,94 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
   return run_global_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
 }
 
+// Shared set-up of the two device-wide-sort matchers (k_global.h, k_hashtable.h); every launch
+// covers the whole batch (pair = blockIdx.y / .z).
+struct GlobalPlan {
+  int nmax, nblk, nmblk;
+  gpc::GpcBatchStrides bs;
+  int32_t *hist, *blkcnt, *gmisc, *rowcnt;
+  size_t esz;
+};
+
+int plan_global(gpc_hip_ctx* c, int W, int H, int npairs, int mode, int cap, bool hashtable, GlobalPlan& g) {
+  const size_t n = (size_t)W * H;
+  g.nmax = 2 * (W - 2 * GPC_R) * (H - 2 * GPC_R);
+  g.nblk = (g.nmax + GS_TILE - 1) / GS_TILE;
+  g.nmblk = (g.nmax + RM_THREADS - 1) / RM_THREADS;
+  g.esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  const size_t recs = (size_t)g.nmax * npairs;
+  for (int i = 0; i < 2; ++i) {
+    CHK(ensure(c, c->gkeys[i], sizeof(uint32_t) * recs));
+    CHK(ensure(c, c->gvals[i], sizeof(uint32_t) * recs));
+    if (hashtable) {
+      CHK(ensure(c, c->hkeys[i], sizeof(uint32_t) * recs));
+      CHK(ensure(c, c->hvals[i], sizeof(uint32_t) * recs));
+    }
+  }
+  CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * g.nblk + g.nmblk) * npairs));
+  CHK(ensure(c, c->gmisc, sizeof(int32_t) * GM_STRIDE * npairs));
+  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2 * npairs));
+  g.hist = (int32_t*)c->ghist.p;
+  g.blkcnt = g.hist + (size_t)256 * g.nblk * npairs;
+  g.gmisc = (int32_t*)c->gmisc.p;
+  g.rowcnt = (int32_t*)c->rowcnt.p;
+  g.bs.codes = (long)(2 * n);
+  g.bs.recs = g.nmax;
+  g.bs.hist = (long)256 * g.nblk;
+  g.bs.blk = g.nmblk;
+  g.bs.out = (long)cap * (long)g.esz;
+  g.bs.rows = 2 * H;
+  return GPC_OK;
+}
+
+// stable LSD radix sort of (keys, vals) by `passes` 8-bit digits; result in buffer index passes & 1
+int radix_passes(gpc_hip_ctx* c, const GlobalPlan& g, int npairs, uint32_t* keys[2], uint32_t* vals[2], int passes) {
+  for (int pass = 0; pass < passes; ++pass) {
+    const int src = pass & 1, dst = src ^ 1;
+    hipLaunchKernelGGL(gpc::k_g_hist, dim3(g.nblk, npairs), dim3(GS_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[src], (const int32_t*)g.gmisc, 8 * pass, g.hist, g.nblk, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.hist, 256 * g.nblk, g.bs.hist);
+    hipLaunchKernelGGL(gpc::k_g_scatter, dim3(g.nblk, npairs), dim3(GS_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[src], (const uint32_t*)vals[src], keys[dst], vals[dst],
+                       (const int32_t*)g.gmisc, 8 * pass, (const int32_t*)g.hist, g.nblk, g.bs);
+  }
+  HIPCHK(c, hipGetLastError());
+  return GPC_OK;
+}
+
 // Non-epipolar mode: one device-wide stable radix sort per pair (k_global.h).
 int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
                      void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
-  const size_t n = (size_t)W * H;
-  const int nmax = 2 * (W - 2 * GPC_R) * (H - 2 * GPC_R);
-  const int nblk = (nmax + GS_TILE - 1) / GS_TILE;
-  const int nmblk = (nmax + RM_THREADS - 1) / RM_THREADS;
-  for (int i = 0; i < 2; ++i) {
-    CHK(ensure(c, c->gkeys[i], sizeof(uint32_t) * (size_t)nmax));
-    CHK(ensure(c, c->gvals[i], sizeof(uint32_t) * (size_t)nmax));
-  }
-  CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * nblk + nmblk)));
-  CHK(ensure(c, c->gmisc, sizeof(int32_t) * 16));
-  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
-  int32_t* hist = (int32_t*)c->ghist.p;
-  int32_t* blkcnt = hist + (size_t)256 * nblk;
-  int32_t* gmisc = (int32_t*)c->gmisc.p;
-  int32_t* rowcnt = (int32_t*)c->rowcnt.p;
+  GlobalPlan g;
+  CHK(plan_global(c, W, H, npairs, mode, cap, false, g));
   const int apply_filter = (mode == 0);
-  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
-  for (int p = 0; p < npairs; ++p) {
-    const uint32_t* codes = (const uint32_t*)c->codes.p + (size_t)p * 2 * n;
-    const int32_t* stats = (const int32_t*)c->stats.p + (size_t)p * 2 * GPC_STAT_STRIDE;
-    uint32_t* keys[2] = {(uint32_t*)c->gkeys[0].p, (uint32_t*)c->gkeys[1].p};
-    uint32_t* vals[2] = {(uint32_t*)c->gvals[0].p, (uint32_t*)c->gvals[1].p};
-    dim3 rgrid(H - 2 * GPC_R, 2);
-    {
-      Timed t(c, KID_GLOBAL_KEYS);
-      hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, rowcnt, stats, gmisc);
-      hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
-                         (const int32_t*)rowcnt, stats, keys[0], vals[0], gmisc);
-      HIPCHK(c, hipGetLastError());
-    }
-    {
-      Timed t(c, KID_GLOBAL_SORT);
-      for (int pass = 0; pass < 4; ++pass) {
-        const int src = pass & 1, dst = src ^ 1;
-        hipLaunchKernelGGL(gpc::k_g_hist, dim3(nblk), dim3(GS_THREADS), 0, c->stream, (const uint32_t*)keys[src],
-                           (const int32_t*)gmisc, 8 * pass, hist, nblk);
-        hipLaunchKernelGGL(gpc::k_g_scan, dim3(1), dim3(1024), 0, c->stream, hist, 256 * nblk);
-        hipLaunchKernelGGL(gpc::k_g_scatter, dim3(nblk), dim3(GS_THREADS), 0, c->stream,
-                           (const uint32_t*)keys[src], (const uint32_t*)vals[src], keys[dst], vals[dst],
-                           (const int32_t*)gmisc, 8 * pass, (const int32_t*)hist, nblk);
-      }
-      HIPCHK(c, hipGetLastError());
-    }
-    {
-      Timed t(c, KID_GLOBAL_MATCH);
-      hipLaunchKernelGGL(gpc::k_g_match_count, dim3(nmblk), dim3(RM_THREADS), 0, c->stream,
-                         (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)gmisc, W,
-                         s->disp_high, s->vertical_tolerance, apply_filter, blkcnt);
-      hipLaunchKernelGGL(gpc::k_g_match_write, dim3(nmblk), dim3(RM_THREADS), 0, c->stream,
-                         (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)gmisc, W,
-                         s->disp_high, s->vertical_tolerance, apply_filter, (const int32_t*)blkcnt, mode,
-                         (void*)((char*)d_out + (size_t)p * cap * esz), cap, d_counts + p, stats,
-                         d_ncand ? d_ncand + 2 * p : nullptr);
-      HIPCHK(c, hipGetLastError());
-    }
+  const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const int32_t* stats = (const int32_t*)c->stats.p;
+  uint32_t* keys[2] = {(uint32_t*)c->gkeys[0].p, (uint32_t*)c->gkeys[1].p};
+  uint32_t* vals[2] = {(uint32_t*)c->gvals[0].p, (uint32_t*)c->gvals[1].p};
+  dim3 rgrid(H - 2 * GPC_R, 2, npairs);
+  {
+    Timed t(c, KID_GLOBAL_KEYS);
+    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, g.rowcnt, stats,
+                       g.gmisc, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+                       (const int32_t*)g.rowcnt, stats, keys[0], vals[0], g.gmisc, g.bs);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    Timed t(c, KID_GLOBAL_SORT);
+    CHK(radix_passes(c, g, npairs, keys, vals, 4));  // 31-bit codes
+  }
+  {
+    Timed t(c, KID_GLOBAL_MATCH);
+    hipLaunchKernelGGL(gpc::k_g_match_count, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
+                       s->disp_high, s->vertical_tolerance, apply_filter, g.blkcnt, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_match_write, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
+                       s->disp_high, s->vertical_tolerance, apply_filter, (const int32_t*)g.blkcnt, mode, d_out, cap,
+                       d_counts, stats, d_ncand, g.bs);
+    HIPCHK(c, hipGetLastError());
   }
   return GPC_OK;
 }
@@ -372,68 +402,44 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
 // useHashtable mode (hashmatch.hpp): stable radix sort by bucket id + one thread per bucket (k_hashtable.h)
 int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
                         void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
-  const size_t n = (size_t)W * H;
-  const int nmax = 2 * (W - 2 * GPC_R) * (H - 2 * GPC_R);
-  const int nblk = (nmax + GS_TILE - 1) / GS_TILE;
-  const int nmblk = (nmax + 255) / 256;
-  for (int i = 0; i < 2; ++i) {
-    CHK(ensure(c, c->hkeys[i], sizeof(uint32_t) * (size_t)nmax));
-    CHK(ensure(c, c->hvals[i], sizeof(uint32_t) * (size_t)nmax));
-  }
-  CHK(ensure(c, c->gkeys[0], sizeof(uint32_t) * (size_t)nmax));
-  CHK(ensure(c, c->gvals[0], sizeof(uint32_t) * (size_t)nmax));
-  CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * nblk + nmblk)));
-  CHK(ensure(c, c->gmisc, sizeof(int32_t) * 16));
-  CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
-  int32_t* hist = (int32_t*)c->ghist.p;
-  int32_t* blkcnt = hist + (size_t)256 * nblk;
-  int32_t* gmisc = (int32_t*)c->gmisc.p;
-  int32_t* rowcnt = (int32_t*)c->rowcnt.p;
+  GlobalPlan g;
+  CHK(plan_global(c, W, H, npairs, mode, cap, true, g));
   const int apply_filter = (mode == 0);
-  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  const int epi = s->epipolar_mode ? 1 : 0;
+  const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const int32_t* stats = (const int32_t*)c->stats.p;
   uint32_t* codes0 = (uint32_t*)c->gkeys[0].p;
   uint32_t* kv0 = (uint32_t*)c->gvals[0].p;
   uint32_t* keys[2] = {(uint32_t*)c->hkeys[0].p, (uint32_t*)c->hkeys[1].p};
   uint32_t* vals[2] = {(uint32_t*)c->hvals[0].p, (uint32_t*)c->hvals[1].p};
-  for (int p = 0; p < npairs; ++p) {
-    const uint32_t* codes = (const uint32_t*)c->codes.p + (size_t)p * 2 * n;
-    const int32_t* stats = (const int32_t*)c->stats.p + (size_t)p * 2 * GPC_STAT_STRIDE;
-    dim3 rgrid(H - 2 * GPC_R, 2);
-    {
-      Timed t(c, KID_GLOBAL_KEYS);
-      hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, rowcnt, stats, gmisc);
-      hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
-                         (const int32_t*)rowcnt, stats, codes0, kv0, gmisc);
-      hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)codes0,
-                         (const uint32_t*)kv0, (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, keys[0], vals[0]);
-      HIPCHK(c, hipGetLastError());
-    }
-    {
-      Timed t(c, KID_GLOBAL_SORT);
-      for (int pass = 0; pass < 3; ++pass) {  // 214673 < 2^18: three 8-bit digits
-        const int src = pass & 1, dst = src ^ 1;
-        hipLaunchKernelGGL(gpc::k_g_hist, dim3(nblk), dim3(GS_THREADS), 0, c->stream, (const uint32_t*)keys[src],
-                           (const int32_t*)gmisc, 8 * pass, hist, nblk);
-        hipLaunchKernelGGL(gpc::k_g_scan, dim3(1), dim3(1024), 0, c->stream, hist, 256 * nblk);
-        hipLaunchKernelGGL(gpc::k_g_scatter, dim3(nblk), dim3(GS_THREADS), 0, c->stream,
-                           (const uint32_t*)keys[src], (const uint32_t*)vals[src], keys[dst], vals[dst],
-                           (const int32_t*)gmisc, 8 * pass, (const int32_t*)hist, nblk);
-      }
-      HIPCHK(c, hipGetLastError());
-    }
-    {
-      Timed t(c, KID_GLOBAL_MATCH);
-      hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)keys[1],
-                         (const uint32_t*)vals[1], (const uint32_t*)codes0, (const uint32_t*)kv0,
-                         (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, s->disp_high, s->vertical_tolerance,
-                         apply_filter, blkcnt, mode, (void*)nullptr, 0, (int32_t*)nullptr, stats, (int32_t*)nullptr);
-      hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(nmblk), dim3(256), 0, c->stream, (const uint32_t*)keys[1],
-                         (const uint32_t*)vals[1], (const uint32_t*)codes0, (const uint32_t*)kv0,
-                         (const int32_t*)gmisc, W, s->epipolar_mode ? 1 : 0, s->disp_high, s->vertical_tolerance,
-                         apply_filter, blkcnt, mode, (void*)((char*)d_out + (size_t)p * cap * esz), cap, d_counts + p,
-                         stats, d_ncand ? d_ncand + 2 * p : nullptr);
-      HIPCHK(c, hipGetLastError());
-    }
+  dim3 rgrid(H - 2 * GPC_R, 2, npairs);
+  {
+    Timed t(c, KID_GLOBAL_KEYS);
+    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, g.rowcnt, stats,
+                       g.gmisc, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+                       (const int32_t*)g.rowcnt, stats, codes0, kv0, g.gmisc, g.bs);
+    hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
+                       (const uint32_t*)codes0, (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, keys[0],
+                       vals[0], g.bs);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    Timed t(c, KID_GLOBAL_SORT);
+    CHK(radix_passes(c, g, npairs, keys, vals, 3));  // 214673 < 2^18: three 8-bit digits -> result in [1]
+  }
+  {
+    Timed t(c, KID_GLOBAL_MATCH);
+    hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
+                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint32_t*)codes0,
+                       (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       apply_filter, g.blkcnt, mode, (void*)nullptr, 0, (int32_t*)nullptr, stats, (int32_t*)nullptr,
+                       g.bs);
+    hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
+                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint32_t*)codes0,
+                       (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       apply_filter, g.blkcnt, mode, d_out, cap, d_counts, stats, d_ncand, g.bs);
+    HIPCHK(c, hipGetLastError());
   }
   return GPC_OK;
 }

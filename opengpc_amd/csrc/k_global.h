@@ -25,18 +25,34 @@ namespace gpc {
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_CHUNK (GS_TILE / GS_WAVES)    // records per wave
 
-// gmisc layout (int32): [0] number of records N, [1] largest right-image code, [2] N_L
+// gmisc layout (int32, GM_STRIDE per pair): [0] number of records N, [1] largest right-image code, [2] N_L
 #define GM_N 0
 #define GM_MAXR 1
 #define GM_NL 2
+#define GM_STRIDE 16
+
+// All kernels of this file (and k_hashtable.h) take the pair from blockIdx.y / .z and find their
+// per-pair slices with these strides, so one launch serves a whole batch.
+struct GpcBatchStrides {
+  long codes;   // u32 words between the code images of consecutive pairs (2*W*H)
+  long recs;    // records (u32 words) per pair in the key / value arrays (nmax)
+  long hist;    // histogram words per pair (256 * nblk)
+  long blk;     // match-block counters per pair (nmblk)
+  long out;     // BYTES between the output arrays of consecutive pairs (cap * element size)
+  int rows;     // rowcnt words per pair (2 * H)
+};
 
 // ---- build the record array from the two code images of one pair --------------------
-// grid: (H - 26, 2)
+// grid: (H - 26, 2, npairs)
 __global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __restrict__ codes, int W, int H,
                                                            int32_t* __restrict__ rowcnt,
                                                            const int32_t* __restrict__ stats,
-                                                           int32_t* __restrict__ gmisc) {
-  const int y = GPC_R + blockIdx.x, side = blockIdx.y;
+                                                           int32_t* __restrict__ gmisc, GpcBatchStrides bs) {
+  const int y = GPC_R + blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
+  codes += pair * bs.codes;
+  rowcnt += pair * bs.rows;
+  stats += pair * 2 * GPC_STAT_STRIDE;
+  gmisc += pair * GM_STRIDE;
   const uint32_t* row = codes + ((long)side * H + y) * W;
   int v = 0;
   for (int x = threadIdx.x; x < W; x += RM_THREADS) v += row[x] != GPC_NOCAND;
@@ -57,14 +73,20 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __res
   }
 }
 
-// grid: (H - 26, 2); runs after k_g_rowcount
+// grid: (H - 26, 2, npairs); runs after k_g_rowcount
 __global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restrict__ codes, int W, int H,
                                                         const int32_t* __restrict__ rowcnt,
                                                         const int32_t* __restrict__ stats,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        int32_t* __restrict__ gmisc) {
+                                                        int32_t* __restrict__ gmisc, GpcBatchStrides bs) {
   __shared__ int s_wcnt[RM_THREADS / 64];
-  const int y = GPC_R + blockIdx.x, side = blockIdx.y;
+  const int y = GPC_R + blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
+  codes += pair * bs.codes;
+  rowcnt += pair * bs.rows;
+  stats += pair * 2 * GPC_STAT_STRIDE;
+  keys += pair * bs.recs;
+  vals += pair * bs.recs;
+  gmisc += pair * GM_STRIDE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int total = block_prefix_rows(rowcnt + side * H, GPC_R, y);
   if (side) total += stats[GPC_STAT_NCAND];  // right records follow all left records
@@ -109,8 +131,11 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned digit, bool v
 // hist[d * nblk + blk] = number of records of tile blk whose digit is d
 __global__ __launch_bounds__(GS_THREADS) void k_g_hist(const uint32_t* __restrict__ keys,
                                                        const int32_t* __restrict__ gmisc, int shift,
-                                                       int32_t* __restrict__ hist, int nblk) {
+                                                       int32_t* __restrict__ hist, int nblk, GpcBatchStrides bs) {
   __shared__ int s_hist[256];
+  keys += blockIdx.y * bs.recs;
+  hist += blockIdx.y * bs.hist;
+  gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,8 +159,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_hist(const uint32_t* __restric
 // owning a contiguous slice: pass 1 sums the slice (coalesced loads, no cross-lane work), the 16
 // slice totals are combined through LDS, pass 2 rescans the slice with a DPP wave scan and a
 // scalar carry.  (~100 KB of counters per radix pass: latency-, not bandwidth-bound.)
-__global__ __launch_bounds__(1024) void k_g_scan(int32_t* __restrict__ data, int total) {
+__global__ __launch_bounds__(1024) void k_g_scan(int32_t* __restrict__ data, int total, long pair_stride) {
   __shared__ int s_tot[16];
+  data += blockIdx.y * pair_stride;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (((total + 15) / 16) + 63) / 64 * 64;
   const int beg = wave * per;
@@ -161,8 +187,15 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __rest
                                                           uint32_t* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out,
                                                           const int32_t* __restrict__ gmisc, int shift,
-                                                          const int32_t* __restrict__ hist, int nblk) {
+                                                          const int32_t* __restrict__ hist, int nblk,
+                                                          GpcBatchStrides bs) {
   __shared__ int s_run[GS_WAVES][256];
+  keys_in += blockIdx.y * bs.recs;
+  vals_in += blockIdx.y * bs.recs;
+  keys_out += blockIdx.y * bs.recs;
+  vals_out += blockIdx.y * bs.recs;
+  hist += blockIdx.y * bs.hist;
+  gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
   const int blk = blockIdx.x;
   if (blk * GS_TILE >= N) return;
@@ -238,8 +271,12 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match_count(const uint32_t* __
                                                               const uint32_t* __restrict__ vals,
                                                               const int32_t* __restrict__ gmisc, int W,
                                                               int disp_high, int vtol, int apply_filter,
-                                                              int32_t* __restrict__ blkcnt) {
+                                                              int32_t* __restrict__ blkcnt, GpcBatchStrides bs) {
   __shared__ int s_part[RM_THREADS / 64];
+  keys += blockIdx.y * bs.recs;
+  vals += blockIdx.y * bs.recs;
+  blkcnt += blockIdx.y * bs.blk;
+  gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
   const int i = blockIdx.x * RM_THREADS + threadIdx.x;
   int4 m;
@@ -262,8 +299,16 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match_write(const uint32_t* __
                                                               void* __restrict__ out, int cap,
                                                               int32_t* __restrict__ count_out,
                                                               const int32_t* __restrict__ stats,
-                                                              int32_t* __restrict__ ncand_out) {
+                                                              int32_t* __restrict__ ncand_out, GpcBatchStrides bs) {
   __shared__ int s_part[RM_THREADS / 64];
+  keys += blockIdx.y * bs.recs;
+  vals += blockIdx.y * bs.recs;
+  blkcnt += blockIdx.y * bs.blk;
+  gmisc += blockIdx.y * GM_STRIDE;
+  stats += blockIdx.y * 2 * GPC_STAT_STRIDE;
+  out = reinterpret_cast<char*>(out) + blockIdx.y * bs.out;
+  count_out += blockIdx.y;
+  if (ncand_out) ncand_out += 2 * blockIdx.y;
   const int N = gmisc[GM_N];
   const int off = block_prefix_rows(blkcnt, 0, blockIdx.x);
   const int i = blockIdx.x * RM_THREADS + threadIdx.x;

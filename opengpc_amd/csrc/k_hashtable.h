@@ -26,7 +26,13 @@ namespace gpc {
 __global__ __launch_bounds__(256) void k_ht_bucket_ids(const uint32_t* __restrict__ codes0,
                                                        const uint32_t* __restrict__ kv0,
                                                        const int32_t* __restrict__ gmisc, int W, int epipolar,
-                                                       uint32_t* __restrict__ skey, uint32_t* __restrict__ sval) {
+                                                       uint32_t* __restrict__ skey, uint32_t* __restrict__ sval,
+                                                       GpcBatchStrides bs) {
+  codes0 += blockIdx.y * bs.recs;
+  kv0 += blockIdx.y * bs.recs;
+  skey += blockIdx.y * bs.recs;
+  sval += blockIdx.y * bs.recs;
+  gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -96,8 +102,20 @@ __global__ __launch_bounds__(256) void k_ht_pairs(const uint32_t* __restrict__ s
                                                   int disp_high, int vtol, int apply_filter,
                                                   int32_t* __restrict__ blkcnt, int mode, void* __restrict__ out, int cap,
                                                   int32_t* __restrict__ count_out, const int32_t* __restrict__ stats,
-                                                  int32_t* __restrict__ ncand_out) {
+                                                  int32_t* __restrict__ ncand_out, GpcBatchStrides bs) {
   __shared__ uint32_t s_w[4];
+  skey += blockIdx.y * bs.recs;
+  sval += blockIdx.y * bs.recs;
+  codes0 += blockIdx.y * bs.recs;
+  kv0 += blockIdx.y * bs.recs;
+  blkcnt += blockIdx.y * bs.blk;
+  gmisc += blockIdx.y * GM_STRIDE;
+  stats += blockIdx.y * 2 * GPC_STAT_STRIDE;
+  if (WRITE) {
+    out = reinterpret_cast<char*>(out) + blockIdx.y * bs.out;
+    count_out += blockIdx.y;
+    if (ncand_out) ncand_out += 2 * blockIdx.y;
+  }
   const int N = gmisc[GM_N];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -253,3 +253,21 @@ def test_hashtable_mode_bucket_overflow_and_triplets(ctx, oracle, forest_paths):
         sg, n, ncand, st = ctx.match_pair(img, img2, g.Settings(5, 128, 1, ep, True, 1))
         assert (nl, nr) == tuple(ncand) and nl > 0
         assert n == len(so) and np.array_equal(sg, so.astype(sg.dtype))
+
+
+@pytest.mark.parametrize("epipolar,hashtable", [(False, False), (True, True), (False, True)])
+def test_batched_device_wide_modes_equal_single(ctx, oracle, forest_paths, epipolar, hashtable):
+    """The non-epipolar and hash-table matchers run one launch per kernel over the whole batch."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    W, H, P = 272, 61, 5
+    ctx.load_forest(forest_paths["tau"], W, H)
+    Ls, Rs = zip(*[synth_pair(W, H, 10 + i, 5 + 3 * i) for i in range(P)])
+    s = g.Settings(5, 128, 1, epipolar, hashtable, 1)
+    out, counts, ncand, st = ctx.match_batch(np.stack(Ls), np.stack(Rs), s, 20000)
+    assert st == 0
+    rc, f = oracle.read_forest(forest_paths["tau"], W, H)
+    for i in range(P):
+        want, nl, nr = oracle.match_pair(Ls[i], Rs[i], f, sparsematch_settings(5, 128, 1, epipolar, hashtable))
+        assert (nl, nr) == tuple(ncand[i]) and counts[i] == len(want)
+        assert np.array_equal(out[i, :counts[i]], want.astype(out.dtype))

@@ -24,6 +24,8 @@ CONFIGS = [
     ("C5 single 3840x2160 stress16x20 (first 32 tests)", 3840, 2160, "stress16x20Forest.txt", 2, 64, 1, True, False),
     ("C2 single 1024x436 Zero global (non-epipolar)", 1024, 436, "defaultZeroForest.txt", 0, 24, 1, False, False),
     ("C2 single 1024x436 Zero epipolar hashtable", 1024, 436, "defaultZeroForest.txt", 0, 24, 1, True, True),
+    ("C2 batch32 1024x436 Zero global (non-epipolar)", 1024, 436, "defaultZeroForest.txt", 0, 24, 32, False, False),
+    ("C2 batch32 1024x436 Zero epipolar hashtable", 1024, 436, "defaultZeroForest.txt", 0, 24, 32, True, True),
 ]
 
 
