@@ -206,13 +206,27 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
 int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, const uint8_t* d_cand,
              int W, int H, int nimg, bool dense, uint32_t* d_codes) {
   if (!c->have_forest) return GPC_E_NO_FOREST;
-  dim3 grid((W + HT_X - 1) / HT_X, (H + HT_Y - 1) / HT_Y, nimg);
+  // tiles per workgroup: each CU holds 2 workgroups (67 KiB of LDS each); walking several
+  // vertically adjacent tiles hides the next window's load latency, but the grid must still fill
+  // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
+  const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H + HT_Y - 1) / HT_Y;
+  int tpw = 1;
+  {
+    long best = -1;
+    for (int t = 1; t <= 8 && t <= tiles_y; ++t) {
+      const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
+      const long rounds = (nwg + 511) / 512;
+      long cost = rounds * t * 16 + ((tiles_y % t) ? 4 : 0) - (t > 1 ? 2 : 0);  // ragged split / no prefetch penalties
+      if (best < 0 || cost < best || (cost == best && t > tpw)) { best = cost; tpw = t; }
+    }
+  }
+  dim3 grid(gx, (tiles_y + tpw - 1) / tpw, nimg);
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, NAIVE ? c->forest_naive : c->forest, st)
+                     d_cand, d_codes, W, H, NAIVE ? c->forest_naive : c->forest, st, tpw)
   if (c->naive) {
     if (tau && dense) LAUNCH_HASH(true, true, true);
     else if (tau) LAUNCH_HASH(true, false, true);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
-                                              GpcForestDev f, int32_t* __restrict__ img_stats) {
+                                              GpcForestDev f, int32_t* __restrict__ img_stats, int tpw) {
   constexpr int RPW = HT_Y / (HT_THREADS / 64);
   __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
   __shared__ int s_cnt, s_last;
@@ -127,34 +127,67 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   const uint8_t* gr = grad + (long)img * n;
   const uint8_t* cm = candmap ? candmap + (long)img * n : nullptr;
   uint32_t* out = codes + (long)img * n;
-  const int tx0 = blockIdx.x * HT_X, ty0 = blockIdx.y * HT_Y;
+  const int tx0 = blockIdx.x * HT_X;
   const int tid = threadIdx.x;
 
   if (tid == 0) { s_cnt = 0; s_last = -1; }
 
-  // ---- stage the smooth window; linear addressing like the reference's unaligned loads,
-  //      bytes outside the buffer read as 0
-  //      copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
-  for (int c = tid; c < HT_ROWS * (HT_STRIDE / 16); c += HT_THREADS) {
-    const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
-    const long k = (long)(ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    uint32_t nx = 0;
-    if (k >= 0 && k + 16 <= n) v = *reinterpret_cast<const uint4*>(sm + k);
-    if (q + 1 < HT_STRIDE / 16 && k + 16 >= 0 && k + 20 <= n) nx = *reinterpret_cast<const uint32_t*>(sm + k + 16);
-    uint8_t* dst = tile + r * HT_STRIDE + q * 16;
-    *reinterpret_cast<uint4*>(dst) = v;
+  // A workgroup walks `tpw` vertically adjacent tiles.  The window of the NEXT tile is fetched
+  // into registers (16-byte coalesced loads) before the current tile's tests run, so the global
+  // latency hides behind ~7 us of VALU/LDS work; it is written to LDS (as 4 byte-shifted copies)
+  // once the current tile is done.
+  constexpr int NCHUNK = HT_ROWS * (HT_STRIDE / 16);
+  constexpr int CPT = (NCHUNK + HT_THREADS - 1) / HT_THREADS;  // chunks per thread
+  uint4 pv[CPT];
+  uint32_t pn[CPT];
+  auto fetch = [&](int ty0) {
 #pragma unroll
-    for (int sft = 1; sft < 4; ++sft) {
-      uint4 w;
-      w.x = __builtin_amdgcn_alignbyte(v.y, v.x, sft);
-      w.y = __builtin_amdgcn_alignbyte(v.z, v.y, sft);
-      w.z = __builtin_amdgcn_alignbyte(v.w, v.z, sft);
-      w.w = __builtin_amdgcn_alignbyte(nx, v.w, sft);
-      *reinterpret_cast<uint4*>(dst + sft * HT_COPY) = w;
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * HT_THREADS;
+      const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
+      // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
+      const long k = (long)(ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
+      pv[i] = make_uint4(0, 0, 0, 0);
+      pn[i] = 0;
+      if (c < NCHUNK) {
+        if (k >= 0 && k + 16 <= n) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
+        if (q + 1 < HT_STRIDE / 16 && k + 16 >= 0 && k + 20 <= n) pn[i] = *reinterpret_cast<const uint32_t*>(sm + k + 16);
+      }
     }
-  }
+  };
+  auto stage = [&]() {  // copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * HT_THREADS;
+      if (c < NCHUNK) {
+        const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
+        uint8_t* dst = tile + r * HT_STRIDE + q * 16;
+        const uint4 v = pv[i];
+        *reinterpret_cast<uint4*>(dst) = v;
+#pragma unroll
+        for (int sft = 1; sft < 4; ++sft) {
+          uint4 w;
+          w.x = __builtin_amdgcn_alignbyte(v.y, v.x, sft);
+          w.y = __builtin_amdgcn_alignbyte(v.z, v.y, sft);
+          w.z = __builtin_amdgcn_alignbyte(v.w, v.z, sft);
+          w.w = __builtin_amdgcn_alignbyte(pn[i], v.w, sft);
+          *reinterpret_cast<uint4*>(dst + sft * HT_COPY) = w;
+        }
+      }
+    }
+  };
+
+  const int tile0 = blockIdx.y * tpw;
+  const int ntiles = (H + HT_Y - 1) / HT_Y;
+  fetch(tile0 * HT_Y);
+  int cnt = 0, last = -1;
+#pragma unroll 1
+  for (int tt = 0; tt < tpw && tile0 + tt < ntiles; ++tt) {
+  const int ty0 = (tile0 + tt) * HT_Y;
+  if (tt) __syncthreads();  // every wave has finished reading the previous window
+  stage();
   __syncthreads();
+  if (tt + 1 < tpw && tile0 + tt + 1 < ntiles) fetch(ty0 + HT_Y);
 
   const int wave = tid >> 6, lane = tid & 63;
   const int x0 = tx0 + 4 * lane;
@@ -196,7 +229,11 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) code[r][j] = 0;
 
+#ifdef HT_EXP_NOCOMPUTE
+  if (W < 0) {
+#else
   if (__ballot(any)) {  // wave-uniform: skip segments with nothing to hash
+#endif
     const int T = f.num_tests;
     const int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
     uint32_t p0[RPW], p1[RPW], p2[RPW], p3[RPW], p8[RPW];
@@ -261,7 +298,6 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   }
 
   // ---- store (16 bytes per lane and row, 1 KiB per wave and row) + statistics
-  int cnt = 0, last = -1;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int y = yw + r;
@@ -278,6 +314,8 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     }
     if (candbits[r]) { cnt += __popc(candbits[r]); last = y; }
   }
+  }  // tiles of this workgroup
+  const int lane = tid & 63;
   if (!DENSE) {
     for (int o = 32; o > 0; o >>= 1) {
       cnt += __shfl_xor(cnt, o);
