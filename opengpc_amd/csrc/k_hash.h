@@ -140,7 +140,13 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   constexpr int CPT = (NCHUNK + HT_THREADS - 1) / HT_THREADS;  // chunks per thread
   uint4 pv[CPT];
   uint32_t pn[CPT];
+  uint32_t pg[RPW];  // gradient bytes of this thread's 4 pixels in its RPW rows of the fetched tile
   auto fetch = [&](int ty0) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int y = ty0 + (tid >> 6) * RPW + r, x = tx0 + 4 * (tid & 63);
+      pg[r] = (x < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (long)y * W + x) : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = tid + i * HT_THREADS;
@@ -186,6 +192,9 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   const int ty0 = (tile0 + tt) * HT_Y;
   if (tt) __syncthreads();  // every wave has finished reading the previous window
   stage();
+  uint32_t gq[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) gq[r] = pg[r];
   __syncthreads();
   if (tt + 1 < tpw && tile0 + tt + 1 < ntiles) fetch(ty0 + HT_Y);
 
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     const int y = yw + r;
     const bool inimg = (x0 < W) && (y < H);
     const long k = (long)y * W + x0;
-    const uint32_t g4 = inimg ? *reinterpret_cast<const uint32_t*>(gr + k) : 0u;
+    const uint32_t g4 = gq[r];
     const uint32_t c4 = cm ? (inimg ? *reinterpret_cast<const uint32_t*>(cm + k) : 0u) : g4;
     uint32_t cb = 0;
     if (y >= GPC_R && y < H - GPC_R) {
