@@ -66,6 +66,7 @@ struct gpc_hip_ctx {
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2];
 
+  int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
   int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
   int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
 
@@ -292,10 +293,12 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
         }
 #undef LAUNCH_BUCKET
       } else if (use_join) {
+        int rpw = c->join_rpw > 0 ? c->join_rpw : 1;
+        const dim3 jgrid((H - 2 * GPC_R + rpw - 1) / rpw, npairs);
 #define LAUNCH_JOIN(SPT, NT)                                                                      \
-  hipLaunchKernelGGL((gpc::k_row_join<SPT, NT>), grid, dim3(NT), join_lds, c->stream,             \
+  hipLaunchKernelGGL((gpc::k_row_join<SPT, NT>), jgrid, dim3(NT), join_lds, c->stream,            \
                      (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
-                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s)
+                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s, rpw)
         if (jnt == 1024) { if (jspt == 4) LAUNCH_JOIN(4, 1024); else if (jspt == 2) LAUNCH_JOIN(2, 1024); else LAUNCH_JOIN(1, 1024); }
         else if (jnt == 512) { if (jspt == 4) LAUNCH_JOIN(4, 512); else if (jspt == 2) LAUNCH_JOIN(2, 512); else LAUNCH_JOIN(1, 512); }
         else { if (jspt == 4) LAUNCH_JOIN(4, 256); else if (jspt == 2) LAUNCH_JOIN(2, 256); else LAUNCH_JOIN(1, 256); }
@@ -529,6 +532,8 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  const char* jr = getenv("GPC_HIP_JOIN_RPW");
+  if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   const char* jn = getenv("GPC_HIP_JOIN_NT");
   if (jn && (atoi(jn) == 256 || atoi(jn) == 512 || atoi(jn) == 1024)) c->join_nt = atoi(jn);
   const char* rm = getenv("GPC_HIP_ROWMATCH");

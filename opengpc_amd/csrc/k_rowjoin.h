@@ -115,7 +115,7 @@ template <int SPT, int NT>
 __global__ __launch_bounds__(NT) void k_row_join(
     const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
-    int log2s) {
+    int log2s, int rpw) {
   constexpr int NB = NT * SPT;
   constexpr int RSHIFT = 31 - ((NT == 256 ? 8 : NT == 512 ? 9 : 10) + (SPT == 1 ? 0 : SPT == 2 ? 1 : SPT == 4 ? 2 : SPT == 8 ? 3 : 4));
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
@@ -130,24 +130,39 @@ __global__ __launch_bounds__(NT) void k_row_join(
   uint32_t* r_key = t_wr;                 // [NB]   matched codes, bucket-contiguous (reuses t_wr)
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int y = GPC_R + blockIdx.x;
   const int pair = blockIdx.y;
   const int hshift = 32 - log2s;
   const uint32_t smask = (uint32_t)S - 1u;
 
+  // A workgroup handles `rpw` consecutive rows; the NEXT row's codes are fetched into registers
+  // while the current row is joined, so only the first row's load latency is exposed.
+  const int row0 = GPC_R + blockIdx.x * rpw;
+  uint32_t ncl[SPT], ncr[SPT];
+  auto fetch_row = [&](int yy) {
+    const uint32_t* rl = codes + ((long)(pair * 2) * H + yy) * W;
+    const uint32_t* rr_ = rl + (long)H * W;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      const int x = j * NT + tid;
+      ncl[j] = (x < W) ? rl[x] : RJ_EMPTY;
+      ncr[j] = (x < W) ? rr_[x] : RJ_EMPTY;
+    }
+  };
+  fetch_row(row0);
+#pragma unroll 1
+  for (int ri = 0; ri < rpw && row0 + ri < H - GPC_R; ++ri) {
+  const int y = row0 + ri;
   RJ_STAMP_INIT();
-  // ---- 0. both rows' loads first (their latency hides behind the table init)
-  const uint32_t* rowl = codes + ((long)(pair * 2) * H + y) * W;
-  const uint32_t* rowr = rowl + (long)H * W;
+  // ---- 0. this row's codes (already in flight), table clear, next row's loads
   uint32_t cl[SPT], kl[SPT], kr[SPT];
   {
     uint32_t cr[SPT];
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-      const int x = j * NT + tid;
-      cl[j] = (x < W) ? rowl[x] : RJ_EMPTY;
-      cr[j] = (x < W) ? rowr[x] : RJ_EMPTY;
+      cl[j] = ncl[j];
+      cr[j] = ncr[j];
     }
+    if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
       for (int i = tid; i < (3 * (S + 1) + 3) / 4; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -275,6 +290,8 @@ __global__ __launch_bounds__(NT) void k_row_join(
   RJ_STAMP(6);
   RJ_STAMP_FLUSH();
   if (tid == 0) rowcnt[rowbase] = (int32_t)r_cnt[NB];
+  __syncthreads();  // the table is cleared again for the next row
+  }  // rows of this workgroup
 }
 
 }  // namespace gpc
