@@ -36,6 +36,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the single-pair and two-stream side measurements (profiling runs: every launch "
+                         "of a kernel then has the same grid, so rocprofv3's averages match the HIP-event ones)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (HIP streams + workspaces) the steps alternate over; 1 = strictly serial steps "
                          "(default: clean per-kernel timing); 2 lets step k+1's HBM-bound kernels overlap step k's "
@@ -248,7 +251,7 @@ def main():
         # the same steps alternating over TWO streams/workspaces (step k+1 overlaps step k); reported
         # beside the serial headline because its per-kernel event times are no longer clean
         two = None
-        if world == 1 and P == 1:
+        if world == 1 and P == 1 and not args.no_extras:
             c2 = g.Context(local_rank)
             c2.load_forest(args.forest, W, H)
             st2 = torch.cuda.Stream(device=dev)
@@ -279,7 +282,7 @@ def main():
         # BASELINE configs[1] taken literally: ONE pair per step (launch/occupancy-bound, reported
         # beside the batched headline, never instead of it)
         single = None
-        if world == 1:
+        if world == 1 and not args.no_extras:
             def step1():
                 ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, 1, settings, d_outs[-1].data_ptr(), cap,
                                        d_cnts[-1].data_ptr(), d_ncs[-1].data_ptr())
