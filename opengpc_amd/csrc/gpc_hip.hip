@@ -66,6 +66,7 @@ struct gpc_hip_ctx {
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2];
 
+  int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
   int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
   int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
@@ -212,15 +213,17 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
   const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H + HT_Y - 1) / HT_Y;
   int tpw = 1;
-  {
-    long best = -1;
-    for (int t = 1; t <= 8 && t <= tiles_y; ++t) {
+  if ((long)gx * tiles_y * nimg >= 2 * 512) {  // small launches keep one tile per workgroup (parallelism first)
+    double best = 1e30;
+    for (int t = 2; t <= 9 && t <= tiles_y; ++t) {
       const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
-      const long rounds = (nwg + 511) / 512;
-      long cost = rounds * t * 16 + ((tiles_y % t) ? 4 : 0) - (t > 1 ? 2 : 0);  // ragged split / no prefetch penalties
-      if (best < 0 || cost < best || (cost == best && t > tpw)) { best = cost; tpw = t; }
+      if (nwg < 512) break;
+      const long slots = (nwg + 511) / 512 * 512;
+      const double score = (double)(slots - nwg) / (double)slots + ((tiles_y % t) ? 0.04 : 0.0);  // idle tail + ragged split
+      if (score < best - 1e-9) { best = score; tpw = t; }
     }
   }
+  if (c->hash_tpw > 0) tpw = c->hash_tpw < tiles_y ? c->hash_tpw : tiles_y;  // GPC_HIP_HASH_TPW (tuning)
   dim3 grid(gx, (tiles_y + tpw - 1) / tpw, nimg);
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
@@ -532,6 +535,8 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+  const char* ht = getenv("GPC_HIP_HASH_TPW");
+  if (ht && atoi(ht) > 0 && atoi(ht) <= 64) c->hash_tpw = atoi(ht);
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   const char* jn = getenv("GPC_HIP_JOIN_NT");
