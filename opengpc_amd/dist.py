@@ -19,7 +19,8 @@ def env_world():
 def init(backend, device=None):
     """Initialises the default process group when WORLD_SIZE > 1.  Returns (rank, world)."""
     rank, world, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    # GPC_FORCE_DIST=1 initialises the group even for a single rank (rehearsal of the RCCL path on a 1-GPU box)
+    if (world > 1 or os.environ.get("GPC_FORCE_DIST")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -37,7 +38,7 @@ def owner_of(pair_index, world):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
@@ -58,7 +59,7 @@ def timed_steps(step, steps, device_sync):
 def gather_stats(values, device="cpu"):
     """all_gather of a short list of floats; returns a [world][len(values)] float64 tensor on the CPU."""
     local = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         out = [torch.zeros_like(local) for _ in range(dist.get_world_size())]
         dist.all_gather(out, local)
         return torch.stack(out).cpu()
