@@ -46,6 +46,20 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask, never more than 16
+    (a one-GPU box's share of its host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(args, W, H):
     """Single-thread CPU time of the same timed region on a bounded sample of the workload.
     Uses the reference's own SSE kernels (oracle/_ref) + a C++ port of the inference.hpp glue
@@ -72,6 +86,28 @@ def cpu_baseline(args, W, H):
             break
     times.sort()
     med = times[len(times) // 2]
+    # all host cores, pairs in parallel: one thread per core, each matching its own
+    # pairs; ctypes releases the GIL for the duration of a call
+    allc = None
+    if use_ref:
+        import threading
+        ncores = host_cores()
+        per = max(2, min(8, int(args.cpu_seconds / 3.0 / med / 1.5)))
+        pairs = [synth_pair(W, H, 1000 + i, 8 + i % 64) for i in range(min(ncores, 16))]
+
+        def work(t):
+            L, R = pairs[t % len(pairs)]
+            for _ in range(per):
+                ref.cpu_baseline_pair(L, R, f, s)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(ncores)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        allc = {"value": round(2.0 * W * H * per * ncores / dt / 1e6, 3), "unit": "Mpix/s", "cores": ncores,
+                "sample": "%d threads x %d pairs, pairs in parallel" % (ncores, per)}
     what = ("reference SSE kernels (filter.hpp via oracle/_ref) + C++ port of the inference.hpp glue "
             "(std::sort on 24-byte descriptors)") if use_ref else "scalar C oracle (oracle/gpc_oracle.c, -O3 -march=native)"
     return {
@@ -81,6 +117,7 @@ def cpu_baseline(args, W, H):
         "kind": "port",
         "ms_per_pair": round(med * 1e3, 3),
         "sample": "%d pairs %dx%d (s=i, D=8+i%%64), median; %s; cold first pair excluded by median" % (len(times), W, H, what),
+        "all_cores": allc,
     }
 
 
@@ -243,6 +280,24 @@ def main():
                     "per-kernel split of 5 extra serial steps; largest there: %s" % (dom_name, P, serial_dom),
             "kernels": kinfo,
         }
+
+        # achievable-copy figure of this box: device-to-device copy of 1 GiB, read + write
+        if world == 1 and not args.no_extras:
+            nb = 1 << 30
+            a = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            copy_gbs = 2.0 * nb * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a, b
+            roofline["copy_measured_GBs"] = round(copy_gbs, 1)
+            roofline["frac_of_copy"] = round(achieved / copy_gbs, 4)
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
