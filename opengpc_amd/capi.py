@@ -4,8 +4,11 @@ Plumbing only: numpy for host buffers, raw integer device pointers for HBM-resid
 batches (typically torch tensors' data_ptr()).  There is no CPU fallback -- if the
 shared library is missing or no gfx950 device is usable, this raises.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -150,16 +153,35 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def _close_live_contexts():
+    """Contexts still open at interpreter exit are closed here, while the HIP runtime is still up;
+    a destructor that reaches the library during interpreter teardown could otherwise call into a
+    runtime that is already being destroyed."""
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_contexts)
+
+
 class Context:
     """One gpc_hip_ctx: one device, one stream, one host thread at a time."""
 
     def __init__(self, device=0):
         self.L = load()
+        self.h = None
         h = C.c_void_p()
         _check(self.L, None, self.L.gpc_hip_create(device, C.byref(h)))
         self.h = h
         self.device = device
         self._pinned = []
+        _live_contexts.add(self)
 
     def close(self):
         if self.h:
@@ -170,6 +192,8 @@ class Context:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():  # atexit already closed what was open; never call HIP from teardown
+            return
         try:
             self.close()
         except Exception:

@@ -64,7 +64,7 @@ struct gpc_hip_ctx {
 
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
-  DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2];
+  DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2], hrec;
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
@@ -349,6 +349,7 @@ int plan_global(gpc_hip_ctx* c, int W, int H, int npairs, int mode, int cap, boo
     if (hashtable) {
       CHK(ensure(c, c->hkeys[i], sizeof(uint32_t) * recs));
       CHK(ensure(c, c->hvals[i], sizeof(uint32_t) * recs));
+      CHK(ensure(c, c->hrec, 2 * sizeof(uint32_t) * recs));
     }
   }
   CHK(ensure(c, c->ghist, sizeof(int32_t) * ((size_t)256 * g.nblk + g.nmblk) * npairs));
@@ -410,6 +411,7 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
     hipLaunchKernelGGL(gpc::k_g_match_count, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
                        (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
                        s->disp_high, s->vertical_tolerance, apply_filter, g.blkcnt, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, g.nmblk, (long)g.bs.blk);
     hipLaunchKernelGGL(gpc::k_g_match_write, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
                        (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
                        s->disp_high, s->vertical_tolerance, apply_filter, (const int32_t*)g.blkcnt, mode, d_out, cap,
@@ -441,7 +443,7 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
                        (const int32_t*)g.rowcnt, stats, codes0, kv0, g.gmisc, g.bs);
     hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
                        (const uint32_t*)codes0, (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, keys[0],
-                       vals[0], g.bs);
+                       vals[0], (uint2*)c->hrec.p, g.bs);
     HIPCHK(c, hipGetLastError());
   }
   {
@@ -451,13 +453,14 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
   {
     Timed t(c, KID_GLOBAL_MATCH);
     hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
-                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint32_t*)codes0,
-                       (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint2*)c->hrec.p, keys[0],
+                       vals[0], (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
                        apply_filter, g.blkcnt, mode, (void*)nullptr, 0, (int32_t*)nullptr, stats, (int32_t*)nullptr,
                        g.bs);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, g.nmblk, (long)g.bs.blk);
     hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
-                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint32_t*)codes0,
-                       (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint2*)c->hrec.p, keys[0],
+                       vals[0], (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
                        apply_filter, g.blkcnt, mode, d_out, cap, d_counts, stats, d_ncand, g.bs);
     HIPCHK(c, hipGetLastError());
   }
@@ -554,7 +557,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1]};
+                    &c->hvals[0], &c->hvals[1], &c->hrec};
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto& s : c->free_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

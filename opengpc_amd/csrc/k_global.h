@@ -310,7 +310,7 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match_write(const uint32_t* __
   count_out += blockIdx.y;
   if (ncand_out) ncand_out += 2 * blockIdx.y;
   const int N = gmisc[GM_N];
-  const int off = block_prefix_rows(blkcnt, 0, blockIdx.x);
+  const int off = blkcnt[blockIdx.x];  // exclusive prefix over the pair's workgroups (k_g_scan between the two passes)
   const int i = blockIdx.x * RM_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int4 m = make_int4(0, 0, 0, 0);
