@@ -42,6 +42,26 @@ struct GpcForestDev {
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
+// Pixel index k = y*W + x  ->  (x, y) without an integer division: for k < 2^31,
+// k / W == umulhi(k, ceil(2^(31+p) / W)) >> (p - 1) with p = ceil(log2 W)  (Granlund & Montgomery).
+struct GpcDivW {
+  int W;
+  uint32_t magic;
+  int sh;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int divw(uint32_t k, const GpcDivW& d) { return (int)(__umulhi(k, d.magic) >> d.sh); }
+#endif
+inline GpcDivW make_divw(int W) {
+  int p = 1;
+  while ((1 << p) < W) ++p;
+  GpcDivW d;
+  d.W = W;
+  d.magic = (uint32_t)(((1ull << (31 + p)) + (unsigned long long)W - 1ull) / (unsigned long long)W);
+  d.sh = p - 1;
+  return d;
+}
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }

@@ -408,14 +408,16 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
-    hipLaunchKernelGGL(gpc::k_g_match_count, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
-                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
-                       s->disp_high, s->vertical_tolerance, apply_filter, g.blkcnt, g.bs);
-    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, g.nmblk, (long)g.bs.blk);
-    hipLaunchKernelGGL(gpc::k_g_match_write, dim3(g.nmblk, npairs), dim3(RM_THREADS), 0, c->stream,
-                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, W,
-                       s->disp_high, s->vertical_tolerance, apply_filter, (const int32_t*)g.blkcnt, mode, d_out, cap,
-                       d_counts, stats, d_ncand, g.bs);
+    const int ngm = (g.nmax + GMT_TILE - 1) / GMT_TILE;  // <= nmblk, so the match-block counters are large enough
+    hipLaunchKernelGGL((gpc::k_g_match<false>), dim3(ngm, npairs), dim3(RM_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, make_divw(W),
+                       s->disp_high, s->vertical_tolerance, apply_filter, g.blkcnt, mode, (void*)nullptr, 0,
+                       (int32_t*)nullptr, stats, (int32_t*)nullptr, g.bs);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, ngm, (long)g.bs.blk);
+    hipLaunchKernelGGL((gpc::k_g_match<true>), dim3(ngm, npairs), dim3(RM_THREADS), 0, c->stream,
+                       (const uint32_t*)keys[0], (const uint32_t*)vals[0], (const int32_t*)g.gmisc, make_divw(W),
+                       s->disp_high, s->vertical_tolerance, apply_filter, g.blkcnt, mode, d_out, cap, d_counts, stats,
+                       d_ncand, g.bs);
     HIPCHK(c, hipGetLastError());
   }
   return GPC_OK;
@@ -442,7 +444,7 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
     hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
                        (const int32_t*)g.rowcnt, stats, codes0, kv0, g.gmisc, g.bs);
     hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
-                       (const uint32_t*)codes0, (const uint32_t*)kv0, (const int32_t*)g.gmisc, W, epi, keys[0],
+                       (const uint32_t*)codes0, (const uint32_t*)kv0, (const int32_t*)g.gmisc, make_divw(W), epi, keys[0],
                        vals[0], (uint2*)c->hrec.p, g.bs);
     HIPCHK(c, hipGetLastError());
   }
@@ -452,15 +454,16 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
-    hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
+    const int nhp = (g.nmax + HP_TILE - 1) / HP_TILE;  // <= nmblk, so the match-block counters are large enough
+    hipLaunchKernelGGL((gpc::k_ht_pairs<false>), dim3(nhp, npairs), dim3(HP_THREADS), 0, c->stream,
                        (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint2*)c->hrec.p, keys[0],
-                       vals[0], (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       vals[0], (const int32_t*)g.gmisc, make_divw(W), epi, s->disp_high, s->vertical_tolerance,
                        apply_filter, g.blkcnt, mode, (void*)nullptr, 0, (int32_t*)nullptr, stats, (int32_t*)nullptr,
                        g.bs);
-    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, g.nmblk, (long)g.bs.blk);
-    hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, npairs), dim3(1024), 0, c->stream, g.blkcnt, nhp, (long)g.bs.blk);
+    hipLaunchKernelGGL((gpc::k_ht_pairs<true>), dim3(nhp, npairs), dim3(HP_THREADS), 0, c->stream,
                        (const uint32_t*)keys[1], (const uint32_t*)vals[1], (const uint2*)c->hrec.p, keys[0],
-                       vals[0], (const int32_t*)g.gmisc, W, epi, s->disp_high, s->vertical_tolerance,
+                       vals[0], (const int32_t*)g.gmisc, make_divw(W), epi, s->disp_high, s->vertical_tolerance,
                        apply_filter, g.blkcnt, mode, d_out, cap, d_counts, stats, d_ncand, g.bs);
     HIPCHK(c, hipGetLastError());
   }

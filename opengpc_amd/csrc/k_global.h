@@ -19,8 +19,12 @@
 
 namespace gpc {
 
-#define GS_THREADS 256
+#ifndef GS_THREADS
+#define GS_THREADS 512
+#endif
+#ifndef GS_ITEMS
 #define GS_ITEMS 8
+#endif
 #define GS_TILE (GS_THREADS * GS_ITEMS)  // records per workgroup and pass
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_CHUNK (GS_TILE / GS_WAVES)    // records per wave
@@ -139,20 +143,27 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_hist(const uint32_t* __restric
   const int N = gmisc[GM_N];
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  s_hist[tid] = 0;
+  if (tid < 256) s_hist[tid] = 0;
   __syncthreads();
   const int base = blk * GS_TILE + wave * GS_CHUNK;
   if (blk * GS_TILE < N) {
+    uint32_t k[GS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GS_ITEMS; ++r) {
+      const int i = base + r * 64 + lane;
+      k[r] = (i < N) ? keys[i] : 0u;
+    }
+#pragma unroll
     for (int r = 0; r < GS_ITEMS; ++r) {
       const int i = base + r * 64 + lane;
       const bool valid = i < N;
-      const unsigned digit = valid ? ((keys[i] >> shift) & 0xFFu) : 0u;
+      const unsigned digit = (k[r] >> shift) & 0xFFu;
       const unsigned long long peers = digit_peers(digit, valid);
       if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&s_hist[digit], __popcll(peers));
     }
   }
   __syncthreads();
-  hist[tid * nblk + blk] = s_hist[tid];
+  if (tid < 256) hist[tid * nblk + blk] = s_hist[tid];
 }
 
 // exclusive scan of `total` ints in place; one workgroup of 1024 threads = 16 waves, each wave
@@ -182,6 +193,9 @@ __global__ __launch_bounds__(1024) void k_g_scan(int32_t* __restrict__ data, int
   }
 }
 
+// One stable scatter pass.  The tile's records are first put in digit order in LDS (stable: wave,
+// round, lane order = record order), then written out by consecutive threads, so that every run of
+// a digit leaves the workgroup as one contiguous, coalesced piece.
 __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out,
@@ -189,7 +203,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __rest
                                                           const int32_t* __restrict__ gmisc, int shift,
                                                           const int32_t* __restrict__ hist, int nblk,
                                                           GpcBatchStrides bs) {
-  __shared__ int s_run[GS_WAVES][256];
+  __shared__ uint32_t s_k[GS_TILE], s_v[GS_TILE];
+  __shared__ int s_run[GS_WAVES][256];  // counts per (wave, digit) -> tile-local start of that wave's run
+  __shared__ int s_gofs[256];           // global position of the tile's first record of digit d, minus its local start
+  __shared__ uint32_t s_w[4];
   keys_in += blockIdx.y * bs.recs;
   vals_in += blockIdx.y * bs.recs;
   keys_out += blockIdx.y * bs.recs;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __rest
   const int blk = blockIdx.x;
   if (blk * GS_TILE >= N) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int w = 0; w < GS_WAVES; ++w) s_run[w][tid] = 0;
+  for (int i = tid; i < GS_WAVES * 256; i += GS_THREADS) (&s_run[0][0])[i] = 0;
   __syncthreads();
 
   // pass A: every wave counts the digits of its own contiguous chunk (records stay in registers)
@@ -212,131 +229,170 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __rest
     const bool valid = i < N;
     k[r] = valid ? keys_in[i] : 0u;
     v[r] = valid ? vals_in[i] : 0u;
-    const unsigned digit = (k[r] >> shift) & 0xFFu;
-    const unsigned long long peers = digit_peers(digit, valid);
-    if (valid && (peers & lanemask_lt()) == 0) s_run[wave][digit] += __popcll(peers);
   }
-  __syncthreads();
-  // s_run[w][d] <- global start of digit d for this tile + records of earlier waves
-  {
-    int acc = hist[tid * nblk + blk];
-    for (int w = 0; w < GS_WAVES; ++w) {
-      const int c = s_run[w][tid];
-      s_run[w][tid] = acc;
-      acc += c;
-    }
-  }
-  __syncthreads();
-  // pass B: stable ranks in (wave, round, lane) order == record order
 #pragma unroll
   for (int r = 0; r < GS_ITEMS; ++r) {
     const int i = base + r * 64 + lane;
     const bool valid = i < N;
     const unsigned digit = (k[r] >> shift) & 0xFFu;
     const unsigned long long peers = digit_peers(digit, valid);
-    int pos = 0;
-    if (valid) pos = s_run[wave][digit] + __popcll(peers & lanemask_lt());
+    if (valid && (peers & lanemask_lt()) == 0) s_run[wave][digit] += __popcll(peers);
+  }
+  __syncthreads();
+  // digit d (thread d): runs of the waves one behind the other; then the digits one behind the other
+  uint32_t dcount = 0;
+  if (tid < 256) {
+    int acc = 0;
+    for (int w = 0; w < GS_WAVES; ++w) {
+      const int c = s_run[w][tid];
+      s_run[w][tid] = acc;
+      acc += c;
+    }
+    dcount = (uint32_t)acc;
+    const uint32_t incl = wave_incl_scan(dcount);
+    if (lane == 63) s_w[wave] = incl;
+    dcount = incl - dcount;  // exclusive within the wave
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t lstart = dcount;
+    for (int w = 0; w < wave; ++w) lstart += s_w[w];
+    s_gofs[tid] = hist[tid * nblk + blk] - (int)lstart;
+    for (int w = 0; w < GS_WAVES; ++w) s_run[w][tid] += (int)lstart;
+  }
+  __syncthreads();
+  // pass B: stable tile-local ranks in (wave, round, lane) order == record order
+#pragma unroll
+  for (int r = 0; r < GS_ITEMS; ++r) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < N;
+    const unsigned digit = (k[r] >> shift) & 0xFFu;
+    const unsigned long long peers = digit_peers(digit, valid);
+    int lpos = 0;
+    if (valid) lpos = s_run[wave][digit] + __popcll(peers & lanemask_lt());
     // all lanes of the wave have read s_run before the leaders update it
     __builtin_amdgcn_wave_barrier();
     if (valid) {
-      keys_out[pos] = k[r];
-      vals_out[pos] = v[r];
+      s_k[lpos] = k[r];
+      s_v[lpos] = v[r];
       if ((peers & lanemask_lt()) == 0) s_run[wave][digit] += __popcll(peers);
     }
     __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();
+  const int cnt = min(GS_TILE, N - blk * GS_TILE);
+#pragma unroll
+  for (int r = 0; r < GS_ITEMS; ++r) {
+    const int i = r * GS_THREADS + tid;
+    if (i < cnt) {
+      const uint32_t kk = s_k[i];
+      const int pos = s_gofs[(kk >> shift) & 0xFFu] + i;
+      keys_out[pos] = kk;
+      vals_out[pos] = s_v[i];
+    }
+  }
 }
 
 // ---- matches off the sorted records -----------------------------------------------------
-__device__ __forceinline__ bool g_match_at(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                           int i, int N, int W, uint32_t tail_code, int disp_high, int vtol,
-                                           int apply_filter, int4& m) {
-  const uint32_t code = keys[i];
-  const uint32_t v0 = vals[i];
-  if (v0 >> 31) return false;  // right record
-  const bool prev_same = (i > 0) && keys[i - 1] == code;
-  const bool n1r = (i + 1 < N) && keys[i + 1] == code && (vals[i + 1] >> 31);
+#define GMT_RPT 4                          // sorted records per thread
+#define GMT_TILE (RM_THREADS * GMT_RPT)    // sorted records per workgroup
+
+// Record i (staged in LDS: s_k[q] / s_v[q] hold record j0 - 1 + q) is a left record whose code
+// occurs once on the left and once on the right (tail quirk: once + twice for the largest right code).
+__device__ __forceinline__ bool g_match_at(const uint32_t* s_k, const uint32_t* s_v, int q, const GpcDivW& wd,
+                                           uint32_t tail_code, int disp_high, int vtol, int apply_filter, int4& m) {
+  const uint32_t code = s_k[q];
+  const uint32_t v0 = s_v[q];
+  if (code == 0xFFFFFFFFu || (v0 >> 31)) return false;  // beyond the last record / right record
+  const bool prev_same = s_k[q - 1] == code;
+  const bool n1r = s_k[q + 1] == code && (s_v[q + 1] >> 31);
   if (prev_same || !n1r) return false;
-  const bool n2 = (i + 2 < N) && keys[i + 2] == code;
-  const bool n3 = (i + 3 < N) && keys[i + 3] == code;
+  const bool n2 = s_k[q + 2] == code;
+  const bool n3 = s_k[q + 3] == code;
   const bool ok = (code == tail_code) ? (n2 && !n3) : !n2;
   if (!ok) return false;
-  const int kl = (int)(v0 & 0x7FFFFFFFu), kr = (int)(vals[i + 1] & 0x7FFFFFFFu);
-  m = make_int4(kl % W, kl / W, kr % W, kr / W);
+  const int kl = (int)(v0 & 0x7FFFFFFFu), kr = (int)(s_v[q + 1] & 0x7FFFFFFFu);
+  const int yl = divw((uint32_t)kl, wd), yr = divw((uint32_t)kr, wd);
+  m = make_int4(kl - yl * wd.W, yl, kr - yr * wd.W, yr);
   if (apply_filter && (abs(m.y - m.w) > vtol || abs(m.x - m.z) > disp_high)) return false;
   return true;
 }
 
-__global__ __launch_bounds__(RM_THREADS) void k_g_match_count(const uint32_t* __restrict__ keys,
-                                                              const uint32_t* __restrict__ vals,
-                                                              const int32_t* __restrict__ gmisc, int W,
-                                                              int disp_high, int vtol, int apply_filter,
-                                                              int32_t* __restrict__ blkcnt, GpcBatchStrides bs) {
-  __shared__ int s_part[RM_THREADS / 64];
+// pass A (!WRITE): matches per workgroup -> blkcnt (then scanned exclusively by k_g_scan);
+// pass B (WRITE): the matches themselves, in sorted order.  A workgroup stages GMT_TILE records
+// (+1 before, +3 after) in LDS with coalesced loads; a thread owns GMT_RPT consecutive records.
+template <bool WRITE>
+__global__ __launch_bounds__(RM_THREADS) void k_g_match(const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals,
+                                                        const int32_t* __restrict__ gmisc, GpcDivW wd,
+                                                        int disp_high, int vtol, int apply_filter,
+                                                        int32_t* __restrict__ blkcnt, int mode,
+                                                        void* __restrict__ out, int cap,
+                                                        int32_t* __restrict__ count_out,
+                                                        const int32_t* __restrict__ stats,
+                                                        int32_t* __restrict__ ncand_out, GpcBatchStrides bs) {
+  __shared__ uint32_t s_k[GMT_TILE + 4], s_v[GMT_TILE + 4];
+  __shared__ uint32_t s_w[RM_THREADS / 64];
   keys += blockIdx.y * bs.recs;
   vals += blockIdx.y * bs.recs;
   blkcnt += blockIdx.y * bs.blk;
   gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
-  const int i = blockIdx.x * RM_THREADS + threadIdx.x;
-  int4 m;
-  const bool hit = (i < N) && g_match_at(keys, vals, i, N, W, (uint32_t)gmisc[GM_MAXR], disp_high, vtol, apply_filter, m);
-  const unsigned long long b = __ballot(hit);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = __popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < RM_THREADS / 64; ++w) s += s_part[w];
-    blkcnt[blockIdx.x] = s;
+  const uint32_t tail_code = (uint32_t)gmisc[GM_MAXR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * GMT_TILE;
+  for (int q = tid; q < GMT_TILE + 4; q += RM_THREADS) {
+    const int j = j0 - 1 + q;
+    const bool in = j >= 0 && j < N;
+    s_k[q] = in ? keys[j] : 0xFFFFFFFFu;  // never a code (codes have 31 bits)
+    s_v[q] = in ? vals[j] : 0u;
   }
-}
-
-__global__ __launch_bounds__(RM_THREADS) void k_g_match_write(const uint32_t* __restrict__ keys,
-                                                              const uint32_t* __restrict__ vals,
-                                                              const int32_t* __restrict__ gmisc, int W,
-                                                              int disp_high, int vtol, int apply_filter,
-                                                              const int32_t* __restrict__ blkcnt, int mode,
-                                                              void* __restrict__ out, int cap,
-                                                              int32_t* __restrict__ count_out,
-                                                              const int32_t* __restrict__ stats,
-                                                              int32_t* __restrict__ ncand_out, GpcBatchStrides bs) {
-  __shared__ int s_part[RM_THREADS / 64];
-  keys += blockIdx.y * bs.recs;
-  vals += blockIdx.y * bs.recs;
-  blkcnt += blockIdx.y * bs.blk;
-  gmisc += blockIdx.y * GM_STRIDE;
+  __syncthreads();
+  uint32_t hits = 0u;
+#pragma unroll
+  for (int k = 0; k < GMT_RPT; ++k) {
+    int4 m;
+    if (g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, wd, tail_code, disp_high, vtol, apply_filter, m)) hits |= 1u << k;
+  }
+  const uint32_t cnt = (uint32_t)__popc(hits);
+  const uint32_t incl = wave_incl_scan(cnt);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t base = incl - cnt, total = 0;
+  for (int w = 0; w < RM_THREADS / 64; ++w) {
+    if (w < wave) base += s_w[w];
+    total += s_w[w];
+  }
+  if (!WRITE) {
+    if (tid == 0) blkcnt[blockIdx.x] = (int32_t)total;
+    return;
+  }
   stats += blockIdx.y * 2 * GPC_STAT_STRIDE;
   out = reinterpret_cast<char*>(out) + blockIdx.y * bs.out;
-  count_out += blockIdx.y;
-  if (ncand_out) ncand_out += 2 * blockIdx.y;
-  const int N = gmisc[GM_N];
-  const int off = blkcnt[blockIdx.x];  // exclusive prefix over the pair's workgroups (k_g_scan between the two passes)
-  const int i = blockIdx.x * RM_THREADS + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int4 m = make_int4(0, 0, 0, 0);
-  const bool hit = (i < N) && g_match_at(keys, vals, i, N, W, (uint32_t)gmisc[GM_MAXR], disp_high, vtol, apply_filter, m);
-  const unsigned long long b = __ballot(hit);
-  if (lane == 0) s_part[wave] = __popcll(b);
-  __syncthreads();
-  int pos = off + __popcll(b & lanemask_lt());
-  for (int w = 0; w < wave; ++w) pos += s_part[w];
-  if (hit && pos < cap) {
-    if (mode == 0) {
-      uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
-      o[0] = m.x;
-      o[1] = m.y;
-      o[2] = __float_as_uint((float)(m.x - m.z));
-    } else {
-      reinterpret_cast<int4*>(out)[pos] = m;
+  const int off = blkcnt[blockIdx.x];  // exclusive prefix over the pair's workgroups
+  int pos = off + (int)base;
+#pragma unroll
+  for (int k = 0; k < GMT_RPT; ++k)
+    if ((hits >> k) & 1u) {
+      if (pos < cap) {
+        int4 m;
+        (void)g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, wd, tail_code, disp_high, vtol, apply_filter, m);
+        if (mode == 0) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
+          o[0] = m.x;
+          o[1] = m.y;
+          o[2] = __float_as_uint((float)(m.x - m.z));
+        } else {
+          reinterpret_cast<int4*>(out)[pos] = m;
+        }
+      }
+      ++pos;
     }
-  }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    int total = off;
-    for (int w = 0; w < RM_THREADS / 64; ++w) total += s_part[w];
-    *count_out = total;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    count_out[blockIdx.y] = off + (int)total;
     if (ncand_out) {
-      ncand_out[0] = stats[GPC_STAT_NCAND];
-      ncand_out[1] = stats[GPC_STAT_STRIDE + GPC_STAT_NCAND];
+      ncand_out[2 * blockIdx.y + 0] = stats[GPC_STAT_NCAND];
+      ncand_out[2 * blockIdx.y + 1] = stats[GPC_STAT_STRIDE + GPC_STAT_NCAND];
     }
   }
 }

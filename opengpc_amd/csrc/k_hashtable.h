@@ -29,7 +29,7 @@ namespace gpc {
 // rec[i] = (code, kv) interleaved, so that the bucket replay fetches a record with ONE 8-byte gather
 __global__ __launch_bounds__(256) void k_ht_bucket_ids(const uint32_t* __restrict__ codes0,
                                                        const uint32_t* __restrict__ kv0,
-                                                       const int32_t* __restrict__ gmisc, int W, int epipolar,
+                                                       const int32_t* __restrict__ gmisc, GpcDivW wd, int epipolar,
                                                        uint32_t* __restrict__ skey, uint32_t* __restrict__ sval,
                                                        uint2* __restrict__ rec, GpcBatchStrides bs) {
   codes0 += blockIdx.y * bs.recs;
@@ -42,43 +42,50 @@ __global__ __launch_bounds__(256) void k_ht_bucket_ids(const uint32_t* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   unsigned long long state = codes0[i];
-  if (epipolar) state |= (unsigned long long)((kv0[i] & 0x7FFFFFFFu) / (uint32_t)W) << 32;
+  if (epipolar) state |= (unsigned long long)(uint32_t)divw(kv0[i] & 0x7FFFFFFFu, wd) << 32;
   skey[i] = (uint32_t)(state % HM_BUCKETS);
   sval[i] = (uint32_t)i;
   rec[i] = make_uint2(codes0[i], kv0[i]);
 }
 
-#define HP_TILE 256
+#ifndef HP_RPT
+#define HP_RPT 2                        // sorted records per thread (measured: 1 -> 692, 2 -> 536, 4 -> 600, 8 -> 1220 us per 32 pairs)
+#endif
+#define HP_THREADS 256
+#define HP_TILE (HP_THREADS * HP_RPT)   // sorted records per workgroup
 #define HP_SPAN (HP_TILE + HM_CAP - 1)  // a bucket that starts in the tile keeps at most 9 records beyond it
 
-// OrderedLinkedList::getDuplicates (hashmatch.hpp:162-197) on the ordered entries st[0..n) / kv[0..n)
-// (source records have bit 31 of kv clear); emit(kv_source, kv_target) for every pair it reports.
-template <class F>
-__device__ __forceinline__ void ht_walk(const unsigned long long* st, const uint32_t* kv, int n, F&& emit) {
+// OrderedLinkedList::getDuplicates (hashmatch.hpp:162-197) on an ordered list of n <= 10 entries,
+// given as bit masks so that the walk itself touches no memory:
+//   eq bit u = entries u and u+1 hold the same state,  df bit u = they come from different images.
+// Returns the mask of u for which the pair (entry u = source, entry u+1 = target) is reported.
+__device__ __forceinline__ uint32_t ht_walk_bits(uint32_t eq, uint32_t df, int n) {
+  uint32_t emit = 0u;
   int i = 0;
   while (i < n) {
     const int p = i;
     ++i;
-    if (i < n && st[p] == st[i]) {
-      if ((kv[p] ^ kv[i]) >> 31) {
-        const bool e = (i + 1 < n) ? (st[i + 1] != st[i]) : true;
-        if (e) emit(kv[p], kv[i]);
-        if (i + 1 < n && i + 2 >= n) return;  // "last triplet": the reference leaves the bucket
-      } else if (i + 1 < n && ((kv[i] ^ kv[i + 1]) >> 31)) {
+    if (i < n && ((eq >> p) & 1u)) {
+      if ((df >> p) & 1u) {
+        const bool e = (i + 1 < n) ? !((eq >> i) & 1u) : true;
+        if (e) emit |= 1u << p;
+        if (i + 1 < n && i + 2 >= n) break;  // "last triplet": the reference leaves the bucket
+      } else if (i + 1 < n && ((df >> i) & 1u)) {
         ++i;  // skip over a false pair
       }
     }
   }
+  return emit;
 }
 
 // pass A (!WRITE): gathers the records (sval = index into rec), leaves them in sorted order in
 //   scode / skv for pass B, and counts the pairs per workgroup -> blkcnt (scanned by k_g_scan);
 // pass B (WRITE): streams scode / skv and writes the pairs themselves, in bucket order
 template <bool WRITE>
-__global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+__global__ __launch_bounds__(HP_THREADS) void k_ht_pairs(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval,
                                                       const uint2* __restrict__ rec, uint32_t* __restrict__ scode,
                                                       uint32_t* __restrict__ skv,
-                                                      const int32_t* __restrict__ gmisc, int W, int epipolar,
+                                                      const int32_t* __restrict__ gmisc, GpcDivW wd, int epipolar,
                                                       int disp_high, int vtol, int apply_filter,
                                                       int32_t* __restrict__ blkcnt, int mode, void* __restrict__ out, int cap,
                                                       int32_t* __restrict__ count_out, const int32_t* __restrict__ stats,
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
   __shared__ uint32_t s_kv[HP_SPAN];
   __shared__ unsigned long long s_sst[HP_SPAN];   // state, ordered within the bucket (first 10 insertions only)
   __shared__ uint32_t s_skv[HP_SPAN];
-  __shared__ uint32_t s_w[HP_TILE / 64];
+  __shared__ uint32_t s_w[HP_THREADS / 64];
   __shared__ uint32_t s_prev;
   skey += blockIdx.y * bs.recs;
   sval += blockIdx.y * bs.recs;
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
 
   // ---- stage the tile.  Pass A: every thread gathers its own record(s) through the sorted index;
   //      pass B: streams what pass A left behind (already ordered within each bucket)
-  for (int i = tid; i < HP_SPAN; i += HP_TILE) {
+  for (int i = tid; i < HP_SPAN; i += HP_THREADS) {
     const int j = j0 + i;
     uint32_t key = 0xFFFFFFFFu, kv = 0u;
     unsigned long long st = 0ull;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
         st = rc.x;
         kv = rc.y;
       }
-      if (epipolar) st |= (unsigned long long)((kv & 0x7FFFFFFFu) / (uint32_t)W) << 32;
+      if (epipolar) st |= (unsigned long long)(uint32_t)divw(kv & 0x7FFFFFFFu, wd) << 32;
     }
     s_key[i] = key;
     if (WRITE) {
@@ -142,22 +149,29 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
   //      first 10 insertions; each record counts its own place (pass A only; the ordered records
   //      also go to scode / skv for pass B)
   if (!WRITE) {
-    for (int i = tid; i < HP_SPAN; i += HP_TILE) {
+    for (int i = tid; i < HP_SPAN; i += HP_THREADS) {
       const uint32_t key = s_key[i];
       if (key == 0xFFFFFFFFu) continue;
-      int t = 0;  // insertion index within the bucket
-      while (t < HM_CAP && i - t - 1 >= 0 && s_key[i - t - 1] == key) ++t;
+      uint32_t back = 0u;  // same-bucket records right before this one (statically indexed, pipelined reads)
+#pragma unroll
+      for (int u = 1; u <= HM_CAP; ++u) {
+        const bool in = i - u >= 0;
+        back |= (in && s_key[in ? i - u : 0] == key) ? (1u << (u - 1)) : 0u;
+      }
+      const int t = __builtin_ctz(~back);          // insertion index within the bucket
       if (t >= HM_CAP) continue;                   // dropped: the list was full
       const int h = i - t;                         // the bucket's first record
       if (h == 0 && s_prev == key) continue;       // bucket of the previous tile (handled there, in its halo)
       if (h >= HP_TILE) continue;                  // bucket of the next tile
       const unsigned long long st = s_st[i];
       int r = 0;
-      for (int u = 0; u < HM_CAP; ++u) {
+#pragma unroll
+      for (int u = 0; u < HM_CAP; ++u) {  // sorted by bucket: the bucket's records are contiguous from h on
         const int q = h + u;
-        if (q >= HP_SPAN || s_key[q] != key) break;
-        const unsigned long long o = s_st[q];
-        r += (o < st || (o == st && u < t)) ? 1 : 0;
+        const bool in = q < HP_SPAN;
+        const unsigned long long o = s_st[in ? q : 0];
+        const bool same = in && s_key[in ? q : 0] == key;
+        r += (same && (o < st || (o == st && u < t))) ? 1 : 0;
       }
       const uint32_t kv = s_kv[i];
       s_sst[h + r] = st;
@@ -168,30 +182,57 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
     __syncthreads();
   }
 
-  // ---- the thread of a bucket's first record walks its ordered list
-  int n = 0;
-  {
-    const uint32_t key = s_key[tid];
-    const bool head = key != 0xFFFFFFFFu && (tid == 0 ? s_prev != key : s_key[tid - 1] != key);
-    if (head)
-      while (n < HM_CAP && tid + n < HP_SPAN && s_key[tid + n] == key) ++n;
-  }
-  auto passes = [&](uint32_t ks, uint32_t kt, int4& m) {
-    const int a = (int)(ks & 0x7FFFFFFFu), b = (int)(kt & 0x7FFFFFFFu);
-    m = make_int4(a % W, a / W, b % W, b / W);
-    return !apply_filter || (abs(m.y - m.w) <= vtol && abs(m.x - m.z) <= disp_high);
-  };
+  // ---- the thread that owns a bucket's first record walks its ordered list: the <= 10 entries are
+  //      fetched with statically indexed (pipelined) LDS reads, the walk runs on bit masks.
+  //      A thread owns HP_RPT consecutive positions, so thread order == bucket order.
+  uint32_t em[HP_RPT];
   int cnt = 0;
-  ht_walk(s_sst + tid, s_skv + tid, n, [&](uint32_t ks, uint32_t kt) {
-    int4 m;
-    cnt += passes(ks, kt, m) ? 1 : 0;
-  });
+#pragma unroll
+  for (int k = 0; k < HP_RPT; ++k) {
+    const int p = tid * HP_RPT + k;
+    uint32_t emit = 0u;
+    const uint32_t key = s_key[p];
+    const bool head = key != 0xFFFFFFFFu && (p == 0 ? s_prev != key : s_key[p - 1] != key);
+    if (head) {
+      uint32_t same = 0u;
+      unsigned long long e[HM_CAP];
+      uint32_t q[HM_CAP];
+#pragma unroll
+      for (int u = 0; u < HM_CAP; ++u) {
+        const bool in = p + u < HP_SPAN;
+        same |= (in && s_key[in ? p + u : 0] == key) ? (1u << u) : 0u;
+        e[u] = s_sst[in ? p + u : 0];
+        q[u] = s_skv[in ? p + u : 0];
+      }
+      const int n = __builtin_ctz(~same);  // leading entries of this bucket, at most 10 (bit 10 of ~same is set)
+      uint32_t eq = 0u, df = 0u;
+#pragma unroll
+      for (int u = 0; u + 1 < HM_CAP; ++u) {
+        eq |= (e[u] == e[u + 1]) ? (1u << u) : 0u;
+        df |= ((q[u] ^ q[u + 1]) >> 31) << u;
+      }
+      emit = ht_walk_bits(eq, df, n);
+      if (apply_filter) {
+        uint32_t todo = emit;
+        while (todo) {  // the reported pairs only (mostly one)
+          const int u = __builtin_ctz(todo);
+          todo &= todo - 1u;
+          const uint32_t a = s_skv[p + u] & 0x7FFFFFFFu, b = s_skv[p + u + 1] & 0x7FFFFFFFu;
+          const int ya = divw(a, wd), yb = divw(b, wd);
+          const int xa = (int)a - ya * wd.W, xb = (int)b - yb * wd.W;
+          if (!(abs(ya - yb) <= vtol && abs(xa - xb) <= disp_high)) emit &= ~(1u << u);
+        }
+      }
+    }
+    em[k] = emit;
+    cnt += __popc(emit);
+  }
   const uint32_t incl = wave_incl_scan((uint32_t)cnt);
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
   uint32_t base = incl - (uint32_t)cnt;
   uint32_t total = 0;
-  for (int w = 0; w < HP_TILE / 64; ++w) {
+  for (int w = 0; w < HP_THREADS / 64; ++w) {
     if (w < wave) base += s_w[w];
     total += s_w[w];
   }
@@ -201,21 +242,29 @@ __global__ __launch_bounds__(HP_TILE) void k_ht_pairs(const uint32_t* __restrict
   }
   const int off = blkcnt[blockIdx.x];  // exclusive prefix over the pair's workgroups (k_g_scan)
   int pos = off + (int)base;
-  ht_walk(s_sst + tid, s_skv + tid, n, [&](uint32_t ks, uint32_t kt) {
-    int4 m;
-    if (!passes(ks, kt, m)) return;
-    if (pos < cap) {
-      if (mode == 0) {
-        uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
-        o[0] = m.x;
-        o[1] = m.y;
-        o[2] = __float_as_uint((float)(m.x - m.z));
-      } else {
-        reinterpret_cast<int4*>(out)[pos] = m;
+#pragma unroll
+  for (int k = 0; k < HP_RPT; ++k) {
+    uint32_t emit = em[k];
+    while (emit) {
+      const int u = __builtin_ctz(emit);
+      emit &= emit - 1u;
+      if (pos < cap) {
+        const int p = tid * HP_RPT + k + u;
+        const uint32_t a = s_skv[p] & 0x7FFFFFFFu, b = s_skv[p + 1] & 0x7FFFFFFFu;
+        const int ya = divw(a, wd), yb = divw(b, wd);
+        const int4 m = make_int4((int)a - ya * wd.W, ya, (int)b - yb * wd.W, yb);
+        if (mode == 0) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
+          o[0] = m.x;
+          o[1] = m.y;
+          o[2] = __float_as_uint((float)(m.x - m.z));
+        } else {
+          reinterpret_cast<int4*>(out)[pos] = m;
+        }
       }
+      ++pos;
     }
-    ++pos;
-  });
+  }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {
     *count_out = off + (int)total;
     if (ncand_out) {

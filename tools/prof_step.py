@@ -25,6 +25,7 @@ def main():
     L, R = synth_batch(W, H, list(range(B)))
     s = g.Settings.sparsematch()
     s.epipolar_mode = int(epipolar)
+    s.use_hashtable = int(os.environ.get("GPC_PROF_HASHTABLE") is not None)
     cap = (W - 26) * (H - 26)
     for _ in range(steps):
         out, counts, ncand, st = ctx.match_batch(L, R, s, cap)
