@@ -192,14 +192,22 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
   // threshold^2 passes through _mm_set1_epi16 in the SSE build (filter.hpp:418); sobelNaive keeps the int (:159)
   const int thr_sq = c->naive ? (thr & 0xFF) * (thr & 0xFF) : (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
-  dim3 grid((W / PP_PX + PP_TX - 1) / PP_TX, (H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS), nimg);
+  // 8 rows per thread read every raw row 1.25 times; launches that would not fill the device
+  // (a single pair: 56 workgroups) use 2 rows per thread instead -- 4x the workgroups, shorter chains
+  const int gx = (W / PP_PX + PP_TX - 1) / PP_TX;
+  const bool small = (long)gx * ((H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS)) * nimg < 1024;
+  const int rows = small ? PP_ROWS_SMALL : PP_ROWS;
+  dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
-  if (c->naive)
-    hipLaunchKernelGGL(gpc::k_preprocess<true>, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
-                       (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p);
-  else
-    hipLaunchKernelGGL(gpc::k_preprocess<false>, grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1,
-                       (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p);
+#define LAUNCH_PRE(NAIVE, ROWS)                                                                              \
+  hipLaunchKernelGGL((gpc::k_preprocess<NAIVE, ROWS>), grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1, \
+                     (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p)
+  if (c->naive) {
+    if (small) LAUNCH_PRE(true, PP_ROWS_SMALL); else LAUNCH_PRE(true, PP_ROWS);
+  } else {
+    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL); else LAUNCH_PRE(false, PP_ROWS);
+  }
+#undef LAUNCH_PRE
   HIPCHK(c, hipGetLastError());
   return GPC_OK;
 }

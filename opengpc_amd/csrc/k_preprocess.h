@@ -5,8 +5,8 @@
 //
 // HBM-bound streaming kernel: 1 byte read, 2 bytes written per pixel.  One thread owns a
 // PP_PX (8)-pixel-wide column strip (one aligned 8-byte load per row, 8-byte stores) and marches
-// down PP_ROWS rows with a rolling 3-row window in registers, so every raw row is read
-// (PP_ROWS+2)/PP_ROWS times.  An 8-pixel group is the natural unit of the reference's Sobel
+// down ROWS (8; 2 for small launches) rows with a rolling 3-row window in registers, so every raw
+// row is read (ROWS+2)/ROWS times.  An 8-pixel group is the natural unit of the reference's Sobel
 // lane-duplication quirk (4 decisions shown twice per 8 pixels).
 #pragma once
 #include "gpc_device.h"
@@ -14,7 +14,8 @@
 #ifndef PP_PX
 #define PP_PX 8        // pixels per thread along x (8 or 16); measured on MI355X: 8 -> 29.5 us, 16 -> 32.1 us per 64 images
 #endif
-#define PP_ROWS 8      // rows per thread
+#define PP_ROWS 8      // rows per thread (PP_ROWS_SMALL for launches too small to fill the device)
+#define PP_ROWS_SMALL 2
 #define PP_TX 64       // threads along x per block
 #define PP_TY 4        // row strips per block
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
 // smooth/grad: [npairs*sides][H][W]
 // NAIVE = the reference built with SSE=OFF: boxNaive (sum/9) and sobelNaive (C integer division,
 // no lane duplication), both over output positions W+1 .. (H-1)*W (filter.hpp:157-223).
-template <bool NAIVE>
+template <bool NAIVE, int ROWS>
 __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
     uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
 
   const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;
   const int x0 = (blockIdx.x * PP_TX + tx) * PP_PX;
-  const int ys = (blockIdx.y * PP_TY + ty) * PP_ROWS;
+  const int ys = (blockIdx.y * PP_TY + ty) * ROWS;
   if (x0 >= W || ys >= H) return;
 
   // last row the box filter writes: rows come in pairs from y=1 while y < H-3 (filter.hpp:307);
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   pre_load_row<NAIVE>(raw, n, W, H, ys - 1, x0, rows[0]);
   pre_load_row<NAIVE>(raw, n, W, H, ys, x0, rows[1]);
 #pragma unroll
-  for (int i = 0; i < PP_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     const int y = ys + i;
     if (y >= H) break;
     PreRow& up = rows[i % 3];
