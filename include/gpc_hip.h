@@ -161,6 +161,56 @@ int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* ra
                         int width, int height, int npairs, const gpc_settings* settings,
                         gpc_support* out, int cap_per_pair, int32_t* counts, int32_t* ncand);
 
+/* ---- fern training: the scoring loop -------------------------- */
+/* Replaces Fern::evalSplit (Fern.hpp:209-262), Fern::markSplitSamples (Fern.hpp:271-291) and the
+ * level / resample / tau loops of Fern::train (Fern.hpp:312-372) over a device-resident training
+ * set.  A triplet is three 27x27 byte patches (ref, pos, neg), 729 bytes each in the byte order of
+ * Feature::storeAllTriplets (Feature.hpp:247-256); a test is (i, j, tau) with i, j linear indices
+ * into a patch (Feature::params, Feature.hpp:84-89; Feature::getDecisions, Feature.hpp:101-109).
+ * Marks: one byte per triplet, bit 0 = pos.split, bit 1 = neg.split (GPCDescriptor::split).
+ * Hyperplane SAMPLING stays with the caller (Feature::sampleHyperplane draws from std::mt19937);
+ * these entry points score what was drawn. */
+typedef struct gpc_hip_train_set gpc_hip_train_set;
+typedef struct gpc_split {
+  int32_t i, j, tau;
+} gpc_split;
+typedef struct gpc_split_stats { /* splitStats, Fern.hpp:52-68 */
+  double prec, rec, hmean, convcomb;
+  int32_t tp, fp, fn, tot;
+} gpc_split_stats;
+
+/* Uploads `n` triplets (n * 3 * 729 bytes of host memory) and lays them out for the device.
+ * All marks start cleared.  The set belongs to `ctx` and is destroyed with it at the latest. */
+int gpc_hip_train_set_create(gpc_hip_ctx* ctx, const uint8_t* triplets, int n, gpc_hip_train_set** out);
+int gpc_hip_train_set_destroy(gpc_hip_ctx* ctx, gpc_hip_train_set* set);
+int gpc_hip_train_set_size(const gpc_hip_train_set* set);
+/* marks_in != NULL: replace the marks; marks_out != NULL: read them back (after the replacement) */
+int gpc_hip_train_set_marks(gpc_hip_ctx* ctx, gpc_hip_train_set* set, const uint8_t* marks_in, uint8_t* marks_out);
+/* Fern::evalSplit over params[0 .. score_until_level] (at most 64 levels: the reference's code
+ * words have 64 bits).  w1 = OptimizerSettings::w1_. */
+int gpc_hip_train_eval_split(gpc_hip_ctx* ctx, gpc_hip_train_set* set, const gpc_split* params,
+                             int score_until_level, double w1, gpc_split_stats* stats);
+/* Fern::markSplitSamples over params[0 .. num_params) */
+int gpc_hip_train_mark_split_samples(gpc_hip_ctx* ctx, gpc_hip_train_set* set, const gpc_split* params,
+                                     int num_params);
+/* Fern::train for one fern with the hyperplane samples supplied by the caller:
+ * cand[level * num_resamples + k] is the k-th draw of sampleHyperplane at `level` (its tau is
+ * ignored: the loop over [taulo, tauhi) overwrites it, Fern.hpp:341-342).  Keeps the reference's
+ * selection rule (first candidate whose hmean exceeds the float maximum so far; a level on which
+ * nothing scores above 0 inherits the previous level's parameters) and returns per level the
+ * parameters chosen and the statistics train() prints (those of the LAST candidate evaluated).
+ * max_depth <= 64, tauhi - taulo <= 64. */
+int gpc_hip_train_fern(gpc_hip_ctx* ctx, gpc_hip_train_set* set, int max_depth, const gpc_split* cand,
+                       int num_resamples, int taulo, int tauhi, int only_score_non_split, double w1,
+                       gpc_split* fernparams, gpc_split_stats* level_stats);
+/* One level of the above in pieces, for callers that sample adaptively: begin a fern, score
+ * `ncand` candidates of the current level for every tau in [taulo, tauhi) (tp/fp: [ncand][ntau],
+ * fn = *tot - tp - fp), then fix the level's winner. */
+int gpc_hip_train_begin_fern(gpc_hip_ctx* ctx, gpc_hip_train_set* set, int reset_marks);
+int gpc_hip_train_eval_level(gpc_hip_ctx* ctx, gpc_hip_train_set* set, const gpc_split* cand, int ncand,
+                             int taulo, int tauhi, int32_t* tp, int32_t* fp, int32_t* tot);
+int gpc_hip_train_commit_level(gpc_hip_ctx* ctx, gpc_hip_train_set* set, const gpc_split* best, int mark_split);
+
 /* ---- measurement -------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the context's stream.  When enabled every launch of
  * the named kernels is bracketed by hipEvents; gpc_hip_kernel_time returns the summed

@@ -6,8 +6,8 @@ This Python package is plumbing for tests, bench.py and multi-GPU launches: a ct
 binding (capi) and the in-tree build recipe (build).
 """
 from . import build as _build  # noqa: F401
-from .capi import (Context, FilterMask, GpcError, Settings, SUPPORT_DTYPE, CORR_DTYPE, load, parse_forest,
+from .capi import (Context, TrainSet, SPLIT_DTYPE, STATS_DTYPE, FilterMask, GpcError, Settings, SUPPORT_DTYPE, CORR_DTYPE, load, parse_forest,
                    read_forest)
 
-__all__ = ["Context", "FilterMask", "GpcError", "Settings", "SUPPORT_DTYPE", "CORR_DTYPE", "load",
+__all__ = ["Context", "TrainSet", "SPLIT_DTYPE", "STATS_DTYPE", "FilterMask", "GpcError", "Settings", "SUPPORT_DTYPE", "CORR_DTYPE", "load",
            "parse_forest", "read_forest"]

@@ -75,6 +75,9 @@ SYMBOLS = [
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_time",
+    "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
+    "gpc_hip_train_eval_split", "gpc_hip_train_mark_split_samples", "gpc_hip_train_fern",
+    "gpc_hip_train_begin_fern", "gpc_hip_train_eval_level", "gpc_hip_train_commit_level",
 ]
 
 
@@ -121,6 +124,17 @@ def load():
     L.gpc_hip_set_kernel_timing_mask.argtypes = [C.c_void_p, C.c_uint]
     L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]
     L.gpc_hip_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    vp, ci = C.c_void_p, C.c_int
+    L.gpc_hip_train_set_create.argtypes = [vp, vp, ci, C.POINTER(C.c_void_p)]
+    L.gpc_hip_train_set_destroy.argtypes = [vp, vp]
+    L.gpc_hip_train_set_size.argtypes = [vp]
+    L.gpc_hip_train_set_marks.argtypes = [vp, vp, vp, vp]
+    L.gpc_hip_train_eval_split.argtypes = [vp, vp, vp, ci, C.c_double, vp]
+    L.gpc_hip_train_mark_split_samples.argtypes = [vp, vp, vp, ci]
+    L.gpc_hip_train_fern.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, C.c_double, vp, vp]
+    L.gpc_hip_train_begin_fern.argtypes = [vp, vp, ci]
+    L.gpc_hip_train_eval_level.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
+    L.gpc_hip_train_commit_level.argtypes = [vp, vp, vp, ci]
     _lib = L
     return L
 
@@ -147,6 +161,13 @@ def parse_forest(text, width, height):
     fm = FilterMask()
     st = L.gpc_hip_parse_forest(text.encode(), width, height, C.byref(fm))
     return st, fm
+
+
+# training (include/gpc_hip.h): gpc_split = the scoring fields of Feature::params; gpc_split_stats = splitStats
+SPLIT_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("tau", "<i4")])
+STATS_DTYPE = np.dtype([("prec", "<f8"), ("rec", "<f8"), ("hmean", "<f8"), ("convcomb", "<f8"),
+                        ("tp", "<i4"), ("fp", "<i4"), ("fn", "<i4"), ("tot", "<i4")])
+PATCH_BYTES = 729
 
 
 def _ptr(a):
@@ -309,6 +330,11 @@ class Context:
                                                    npairs, C.byref(settings), C.c_void_p(d_out), cap_per_pair,
                                                    C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
 
+    # ---- fern training: the scoring loop
+    def train_set(self, triplets):
+        """Uploads (n, 3, 729) uint8 patch triplets (ref, pos, neg); returns a TrainSet."""
+        return TrainSet(self, triplets)
+
     # ---- measurement
     def enable_kernel_timing(self, on=True, only=None):
         """HIP-event bracketing of kernel launches; `only` = iterable of kernel names to restrict it to."""
@@ -332,3 +358,71 @@ class Context:
             self._ck(self.L.gpc_hip_kernel_time(self.h, i, C.byref(ms), C.byref(n)))
             out[self.L.gpc_hip_kernel_name(i).decode()] = (ms.value, n.value)
         return out
+
+
+class TrainSet:
+    """Device-resident training triplets of one Context (gpc_hip_train_set): Fern::evalSplit,
+    Fern::markSplitSamples and Fern::train (with caller-supplied hyperplane samples) on the GPU."""
+
+    def __init__(self, ctx, triplets):
+        t = np.ascontiguousarray(triplets, np.uint8)
+        if t.ndim != 3 or t.shape[1:] != (3, PATCH_BYTES):
+            raise ValueError("triplets must have shape (n, 3, 729)")
+        self.ctx = ctx
+        self.n = len(t)
+        h = C.c_void_p()
+        ctx._ck(ctx.L.gpc_hip_train_set_create(ctx.h, _ptr(t), self.n, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.gpc_hip_train_set_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def marks(self, new=None):
+        """Reads (and optionally first replaces) the split marks: bit 0 pos.split, bit 1 neg.split."""
+        out = np.empty(self.n, np.uint8)
+        src = None if new is None else np.ascontiguousarray(new, np.uint8)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_set_marks(self.ctx.h, self.h, _ptr(src), _ptr(out)))
+        return out
+
+    def eval_split(self, params, score_until_level, w1):
+        p = np.ascontiguousarray(params, SPLIT_DTYPE)
+        st = np.zeros(1, STATS_DTYPE)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_eval_split(self.ctx.h, self.h, _ptr(p), int(score_until_level),
+                                                         C.c_double(w1), _ptr(st)))
+        return st[0]
+
+    def mark_split_samples(self, params, num_params):
+        p = np.ascontiguousarray(params, SPLIT_DTYPE)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_mark_split_samples(self.ctx.h, self.h, _ptr(p), int(num_params)))
+
+    def train_fern(self, max_depth, cand, num_resamples, taulo, tauhi, only_score_non_split, w1):
+        """cand[level * num_resamples + k] = k-th hyperplane sample of `level`.  Returns (params, stats)."""
+        c = np.ascontiguousarray(cand, SPLIT_DTYPE)
+        if len(c) < max_depth * num_resamples:
+            raise ValueError("need max_depth * num_resamples hyperplane samples")
+        fp = np.zeros(max_depth, SPLIT_DTYPE)
+        st = np.zeros(max_depth, STATS_DTYPE)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_fern(self.ctx.h, self.h, int(max_depth), _ptr(c), int(num_resamples),
+                                                   int(taulo), int(tauhi), int(bool(only_score_non_split)),
+                                                   C.c_double(w1), _ptr(fp), _ptr(st)))
+        return fp, st
+
+    def begin_fern(self, reset_marks):
+        self.ctx._ck(self.ctx.L.gpc_hip_train_begin_fern(self.ctx.h, self.h, int(bool(reset_marks))))
+
+    def eval_level(self, cand, taulo, tauhi):
+        """tp, fp of every (candidate, tau) of the current level and the number of samples that count."""
+        c = np.ascontiguousarray(cand, SPLIT_DTYPE)
+        ntau = tauhi - taulo
+        tp = np.zeros((len(c), max(ntau, 0)), np.int32)
+        fp = np.zeros_like(tp)
+        tot = np.zeros(1, np.int32)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_eval_level(self.ctx.h, self.h, _ptr(c), len(c), int(taulo), int(tauhi),
+                                                         _ptr(tp), _ptr(fp), _ptr(tot)))
+        return tp, fp, int(tot[0])
+
+    def commit_level(self, best, mark_split):
+        b = np.ascontiguousarray(best, SPLIT_DTYPE).reshape(1)
+        self.ctx._ck(self.ctx.L.gpc_hip_train_commit_level(self.ctx.h, self.h, _ptr(b), int(bool(mark_split))))

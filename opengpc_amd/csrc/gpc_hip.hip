@@ -20,6 +20,7 @@
 #include "k_rowbucket.h"
 #include "k_rowjoin.h"
 #include "k_rowmatch.h"
+#include "k_train.h"
 
 namespace {
 
@@ -32,11 +33,12 @@ enum KernelId {
   KID_GLOBAL_KEYS,
   KID_GLOBAL_SORT,
   KID_GLOBAL_MATCH,
+  KID_TRAIN_EVAL,
   KID_COUNT
 };
 const char* const kKernelNames[KID_COUNT] = {
     "k_preprocess", "k_hash", "k_row_match", "k_gather_rows",
-    "k_mask", "k_global_keys", "k_global_sort", "k_global_match"};
+    "k_mask", "k_global_keys", "k_global_sort", "k_global_match", "k_train_eval"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -76,6 +78,19 @@ struct gpc_hip_ctx {
   unsigned timing_mask = 0xFFFFFFFFu;  // which KernelIds are bracketed by events when timing is on
   std::vector<TimedSpan> spans;
   std::vector<TimedSpan> free_spans;
+
+  std::vector<gpc_hip_train_set*> train_sets;  // training sets created on this context
+};
+
+struct gpc_hip_train_set {
+  gpc_hip_ctx* owner = nullptr;
+  int n = 0;
+  long np = 0;                // n rounded up to a multiple of 256
+  uint8_t* planes = nullptr;  // [3][729][np]
+  uint8_t* flags = nullptr;   // [np]
+  int32_t* counts = nullptr;  // scratch: tp/fp per (candidate, tau) + tot
+  gpc::GpcSplit* d_cand = nullptr;
+  size_t counts_cap = 0, cand_cap = 0;
 };
 
 namespace {
@@ -569,6 +584,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
                     &c->hvals[0], &c->hvals[1], &c->hrec};
+  while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto& s : c->free_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -909,6 +925,240 @@ int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR,
   if (n_cand_l) *n_cand_l = nc[0];
   if (n_cand_r) *n_cand_r = nc[1];
   return st;
+}
+
+// ------------------------------------------------------------------ fern training (k_train.h)
+
+namespace {
+
+void split_stats(int tp, int fp, int fn, int tot, double w1, gpc_split_stats* s) {
+  // Fern.hpp:255-261, same expressions in the same order
+  s->tp = tp;
+  s->fp = fp;
+  s->fn = fn;
+  s->tot = tot;
+  const double w2 = 1. - w1;
+  s->prec = ((tp + fp) == 0) ? 0. : double(tp) / (tp + fp);
+  s->rec = ((tp + fn) == 0) ? 0. : double(tp) / (tp + fn);
+  s->hmean = (s->prec + s->rec == 0.) ? 0. : s->prec * s->rec / ((1. - w2) * s->prec + w2 * s->rec);
+  s->convcomb = (1. - w2) * s->prec + w2 * s->rec;
+}
+
+int train_check(gpc_hip_ctx* c, gpc_hip_train_set* t) {
+  if (!c || !t || t->owner != c) return GPC_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  return GPC_OK;
+}
+
+int train_scratch(gpc_hip_ctx* c, gpc_hip_train_set* t, size_t ncounts, size_t ncand) {
+  if (ncounts > t->counts_cap) {
+    if (t->counts) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(t->counts)); t->counts = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&t->counts, sizeof(int32_t) * ncounts));
+    t->counts_cap = ncounts;
+  }
+  if (ncand > t->cand_cap) {
+    if (t->d_cand) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(t->d_cand)); t->d_cand = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&t->d_cand, sizeof(gpc::GpcSplit) * ncand));
+    t->cand_cap = ncand;
+  }
+  return GPC_OK;
+}
+
+bool split_ok(const gpc_split& p) { return p.i >= 0 && p.i < TS_PATCH && p.j >= 0 && p.j < TS_PATCH; }
+
+}  // namespace
+
+int gpc_hip_train_set_create(gpc_hip_ctx* c, const uint8_t* triplets, int n, gpc_hip_train_set** out) {
+  if (!c || !triplets || n <= 0 || !out) return GPC_E_INVALID;
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  gpc_hip_train_set* t = new gpc_hip_train_set();
+  t->owner = c;
+  t->n = n;
+  t->np = ((long)n + 255) / 256 * 256;
+  uint8_t* d_aos = nullptr;
+  const size_t bytes = (size_t)n * 3 * TS_PATCH;
+  auto fail = [&](int st) {
+    if (d_aos) (void)hipFree(d_aos);
+    if (t->planes) (void)hipFree(t->planes);
+    if (t->flags) (void)hipFree(t->flags);
+    delete t;
+    return st;
+  };
+  if (hipMalloc((void**)&d_aos, bytes) != hipSuccess || hipMalloc((void**)&t->planes, (size_t)3 * TS_PATCH * t->np) != hipSuccess ||
+      hipMalloc((void**)&t->flags, (size_t)t->np) != hipSuccess) {
+    snprintf(c->err, sizeof(c->err), "training set of %d triplets: device allocation failed", n);
+    return fail(GPC_E_HIP);
+  }
+  if (hipMemcpyAsync(d_aos, triplets, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(GPC_E_HIP);
+  hipLaunchKernelGGL(gpc::k_ts_transpose, dim3((unsigned)(t->np / 64), 3, 3), dim3(TS_THREADS), 0, c->stream,
+                     (const uint8_t*)d_aos, n, t->np, t->planes);
+  if (hipMemsetAsync(t->flags, 0, (size_t)t->np, c->stream) != hipSuccess) return fail(GPC_E_HIP);
+  hipLaunchKernelGGL(gpc::k_ts_begin, dim3((unsigned)(t->np / TS_THREADS)), dim3(TS_THREADS), 0, c->stream, t->flags, n,
+                     t->np, 1);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return fail(GPC_E_HIP);
+  (void)hipFree(d_aos);
+  c->train_sets.push_back(t);
+  *out = t;
+  return GPC_OK;
+}
+
+int gpc_hip_train_set_destroy(gpc_hip_ctx* c, gpc_hip_train_set* t) {
+  if (!c || !t || t->owner != c) return GPC_E_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (size_t k = 0; k < c->train_sets.size(); ++k)
+    if (c->train_sets[k] == t) { c->train_sets.erase(c->train_sets.begin() + k); break; }
+  if (t->planes) (void)hipFree(t->planes);
+  if (t->flags) (void)hipFree(t->flags);
+  if (t->counts) (void)hipFree(t->counts);
+  if (t->d_cand) (void)hipFree(t->d_cand);
+  delete t;
+  return GPC_OK;
+}
+
+int gpc_hip_train_set_size(const gpc_hip_train_set* t) { return t ? t->n : 0; }
+
+int gpc_hip_train_set_marks(gpc_hip_ctx* c, gpc_hip_train_set* t, const uint8_t* marks_in, uint8_t* marks_out) {
+  CHK(train_check(c, t));
+  uint8_t* d_m = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_m, (size_t)t->n));
+  const dim3 grid((unsigned)((t->n + TS_THREADS - 1) / TS_THREADS));
+  int st = GPC_OK;
+  if (marks_in) {
+    if (hipMemcpyAsync(d_m, marks_in, (size_t)t->n, hipMemcpyHostToDevice, c->stream) != hipSuccess) st = GPC_E_HIP;
+    hipLaunchKernelGGL(gpc::k_ts_set_marks, grid, dim3(TS_THREADS), 0, c->stream, t->flags, (const uint8_t*)d_m, t->n);
+  }
+  if (marks_out && st == GPC_OK) {
+    hipLaunchKernelGGL(gpc::k_ts_get_marks, grid, dim3(TS_THREADS), 0, c->stream, (const uint8_t*)t->flags, d_m, t->n);
+    if (hipMemcpyAsync(marks_out, d_m, (size_t)t->n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = GPC_E_HIP;
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) st = GPC_E_HIP;
+  (void)hipFree(d_m);
+  if (st != GPC_OK) snprintf(c->err, sizeof(c->err), "training set marks: HIP copy failed");
+  return st;
+}
+
+int gpc_hip_train_eval_split(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_split* params, int score_until_level,
+                             double w1, gpc_split_stats* stats) {
+  CHK(train_check(c, t));
+  if (!params || !stats || score_until_level < 0) return GPC_E_INVALID;
+  const int np_ = score_until_level + 1;
+  if (np_ > 64) return GPC_E_UNSUPPORTED;
+  for (int l = 0; l < np_; ++l)
+    if (!split_ok(params[l])) return GPC_E_INVALID;
+  CHK(train_scratch(c, t, 4, 64));
+  HIPCHK(c, hipMemcpyAsync(t->d_cand, params, sizeof(gpc_split) * np_, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(t->counts, 0, sizeof(int32_t) * 4, c->stream));
+  hipLaunchKernelGGL((gpc::k_ts_eval_split<false>), dim3((unsigned)(t->np / TS_THREADS)), dim3(TS_THREADS), 0, c->stream,
+                     (const uint8_t*)t->planes, t->flags, t->n, t->np, (const gpc::GpcSplit*)t->d_cand, np_, t->counts);
+  HIPCHK(c, hipGetLastError());
+  int32_t h[4];
+  HIPCHK(c, hipMemcpyAsync(h, t->counts, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  split_stats(h[0], h[1], h[2], h[3], w1, stats);
+  return GPC_OK;
+}
+
+int gpc_hip_train_mark_split_samples(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_split* params, int num_params) {
+  CHK(train_check(c, t));
+  if (num_params < 0 || (num_params > 0 && !params)) return GPC_E_INVALID;
+  if (num_params > 64) return GPC_E_UNSUPPORTED;
+  for (int l = 0; l < num_params; ++l)
+    if (!split_ok(params[l])) return GPC_E_INVALID;
+  CHK(train_scratch(c, t, 4, 64));
+  if (num_params) HIPCHK(c, hipMemcpyAsync(t->d_cand, params, sizeof(gpc_split) * num_params, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL((gpc::k_ts_eval_split<true>), dim3((unsigned)(t->np / TS_THREADS)), dim3(TS_THREADS), 0, c->stream,
+                     (const uint8_t*)t->planes, t->flags, t->n, t->np, (const gpc::GpcSplit*)t->d_cand, num_params,
+                     (int32_t*)nullptr);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // params may be freed by the caller
+  return GPC_OK;
+}
+
+int gpc_hip_train_begin_fern(gpc_hip_ctx* c, gpc_hip_train_set* t, int reset_marks) {
+  CHK(train_check(c, t));
+  hipLaunchKernelGGL(gpc::k_ts_begin, dim3((unsigned)(t->np / TS_THREADS)), dim3(TS_THREADS), 0, c->stream, t->flags, t->n,
+                     t->np, reset_marks);
+  HIPCHK(c, hipGetLastError());
+  return GPC_OK;
+}
+
+int gpc_hip_train_eval_level(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_split* cand, int ncand, int taulo, int tauhi,
+                             int32_t* tp, int32_t* fp, int32_t* tot) {
+  CHK(train_check(c, t));
+  const int ntau = tauhi - taulo;
+  if (!cand || ncand <= 0 || !tp || !fp || !tot) return GPC_E_INVALID;
+  if (ntau <= 0 || ntau > TS_MAXTAU) return GPC_E_UNSUPPORTED;
+  for (int k = 0; k < ncand; ++k)
+    if (!split_ok(cand[k])) return GPC_E_INVALID;
+  const size_t nc = (size_t)ncand * ntau;
+  CHK(train_scratch(c, t, 2 * nc + 1, (size_t)ncand));
+  HIPCHK(c, hipMemcpyAsync(t->d_cand, cand, sizeof(gpc_split) * ncand, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(t->counts, 0, sizeof(int32_t) * (2 * nc + 1), c->stream));
+  {
+    Timed tm(c, KID_TRAIN_EVAL);
+    hipLaunchKernelGGL(gpc::k_ts_eval_level, dim3((unsigned)((t->np + TS_CHUNK - 1) / TS_CHUNK), ncand), dim3(TS_THREADS), 0,
+                       c->stream, (const uint8_t*)t->planes, (const uint8_t*)t->flags, t->np,
+                       (const gpc::GpcSplit*)t->d_cand, taulo, ntau, t->counts, t->counts + nc);
+  }
+  hipLaunchKernelGGL(gpc::k_ts_tot, dim3((unsigned)((t->np / 4 + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0,
+                     c->stream, (const uint8_t*)t->flags, t->np, t->counts + 2 * nc);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(tp, t->counts, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(fp, t->counts + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(tot, t->counts + 2 * nc, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPC_OK;
+}
+
+int gpc_hip_train_commit_level(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_split* best, int mark_split) {
+  CHK(train_check(c, t));
+  if (!best || !split_ok(*best)) return GPC_E_INVALID;
+  gpc::GpcSplit b = {best->i, best->j, best->tau};
+  hipLaunchKernelGGL(gpc::k_ts_commit, dim3((unsigned)(t->np / TS_THREADS)), dim3(TS_THREADS), 0, c->stream,
+                     (const uint8_t*)t->planes, t->flags, t->n, t->np, b, mark_split);
+  HIPCHK(c, hipGetLastError());
+  return GPC_OK;
+}
+
+int gpc_hip_train_fern(gpc_hip_ctx* c, gpc_hip_train_set* t, int max_depth, const gpc_split* cand, int num_resamples,
+                       int taulo, int tauhi, int only_score_non_split, double w1, gpc_split* fernparams,
+                       gpc_split_stats* level_stats) {
+  CHK(train_check(c, t));
+  if (max_depth <= 0 || !cand || num_resamples < 0 || !fernparams || !level_stats) return GPC_E_INVALID;
+  if (max_depth > 64 || tauhi - taulo > TS_MAXTAU) return GPC_E_UNSUPPORTED;
+  const int ntau = tauhi > taulo ? tauhi - taulo : 0;
+  std::vector<int32_t> tp((size_t)num_resamples * ntau + 1), fp((size_t)num_resamples * ntau + 1);
+  gpc_split_stats stats;
+  memset(&stats, 0, sizeof stats);
+  gpc_split best = {0, 0, 0};                       // SplitParams_t bestParams;            Fern.hpp:316
+  for (int l = 0; l < max_depth; ++l) fernparams[l] = gpc_split{0, 0, 0};  // fernparams.resize(maxDepth)  :318
+  CHK(gpc_hip_train_begin_fern(c, t, only_score_non_split));                // resetMarkOnSamples        :333
+  for (int level = 0; level < max_depth; ++level) {
+    float max_score = 0.f;
+    int32_t tot = 0;
+    if (num_resamples > 0 && ntau > 0)
+      CHK(gpc_hip_train_eval_level(c, t, cand + (size_t)level * num_resamples, num_resamples, taulo, tauhi, tp.data(),
+                                   fp.data(), &tot));
+    for (int k = 0; k < num_resamples; ++k) {
+      fernparams[level] = cand[(size_t)level * num_resamples + k];          // sampleHyperplane          :339
+      for (int q = 0; q < ntau; ++q) {
+        fernparams[level].tau = taulo + q;
+        const int a = tp[(size_t)k * ntau + q], b = fp[(size_t)k * ntau + q];
+        split_stats(a, b, tot - a - b, tot, w1, &stats);                   // evalSplit                  :343
+        if (stats.hmean > max_score) {                                      // double against float       :346
+          best = fernparams[level];
+          max_score = (float)stats.hmean;
+        }
+      }
+    }
+    fernparams[level] = best;                                               // :352 (also when nothing scored above 0)
+    CHK(gpc_hip_train_commit_level(c, t, &best, only_score_non_split));     // markSplitSamples(level)    :355
+    level_stats[level] = stats;                                             // what train() prints        :357
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPC_OK;
 }
 
 // ------------------------------------------------------------------ measurement

@@ -44,6 +44,11 @@ class Settings(C.Structure):
 
 SUPPORT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("d", "<f4")])
 CORR_DTYPE = np.dtype([("sx", "<i4"), ("sy", "<i4"), ("tx", "<i4"), ("ty", "<i4")])
+# training (oracle/gpc_oracle_train.h): Feature::params fields used by scoring; splitStats
+SPLIT_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("tau", "<i4")])
+STATS_DTYPE = np.dtype([("prec", "<f8"), ("rec", "<f8"), ("hmean", "<f8"), ("convcomb", "<f8"),
+                        ("tp", "<i4"), ("fp", "<i4"), ("fn", "<i4"), ("tot", "<i4")])
+PATCH = 729
 
 
 def build(fast=False):
@@ -87,6 +92,40 @@ class Oracle:
         L.gpc_oracle_hash_correspondences.restype = C.c_int
         L.gpc_oracle_rectified_filter.restype = C.c_int
         L.gpc_oracle_match_pair.restype = C.c_int
+
+    # ---- training scoring loop (parity unpinned, see gpc_oracle_train.h)
+    def eval_split(self, triplets, marks, params, score_until_level, w1):
+        """Fern::evalSplit.  triplets: (n, 3, 729) u8; marks: (n,) u8; params: SPLIT_DTYPE array."""
+        t = np.ascontiguousarray(triplets, np.uint8)
+        m = np.ascontiguousarray(marks, np.uint8)
+        p = np.ascontiguousarray(params, SPLIT_DTYPE)
+        out = np.zeros(1, STATS_DTYPE)
+        self.lib.gpc_oracle_eval_split(C.c_void_p(t.ctypes.data), C.c_void_p(m.ctypes.data), C.c_int(len(t)),
+                                       C.c_void_p(p.ctypes.data), C.c_int(score_until_level), C.c_double(w1),
+                                       C.c_void_p(out.ctypes.data))
+        return out[0]
+
+    def mark_split_samples(self, triplets, marks, params, num_params):
+        """Fern::markSplitSamples; marks is updated in place."""
+        t = np.ascontiguousarray(triplets, np.uint8)
+        p = np.ascontiguousarray(params, SPLIT_DTYPE)
+        assert marks.dtype == np.uint8 and marks.flags.c_contiguous
+        self.lib.gpc_oracle_mark_split_samples(C.c_void_p(t.ctypes.data), C.c_void_p(marks.ctypes.data),
+                                               C.c_int(len(t)), C.c_void_p(p.ctypes.data), C.c_int(num_params))
+
+    def train_fern(self, triplets, marks, max_depth, cand, num_resamples, taulo, tauhi, only_non_split, w1):
+        """Fern::train with injected hyperplane samples cand[level * num_resamples + k]."""
+        t = np.ascontiguousarray(triplets, np.uint8)
+        c = np.ascontiguousarray(cand, SPLIT_DTYPE)
+        assert len(c) >= max_depth * num_resamples
+        assert marks.dtype == np.uint8 and marks.flags.c_contiguous
+        fp = np.zeros(max_depth, SPLIT_DTYPE)
+        st = np.zeros(max_depth, STATS_DTYPE)
+        self.lib.gpc_oracle_train_fern(C.c_void_p(t.ctypes.data), C.c_void_p(marks.ctypes.data), C.c_int(len(t)),
+                                       C.c_int(max_depth), C.c_void_p(c.ctypes.data), C.c_int(num_resamples),
+                                       C.c_int(taulo), C.c_int(tauhi), C.c_int(int(only_non_split)), C.c_double(w1),
+                                       C.c_void_p(fp.ctypes.data), C.c_void_p(st.ctypes.data))
+        return fp, st
 
     # ---- inputs / checksums
     def synth_pair(self, W, H, s=0, D=24):
