@@ -105,6 +105,15 @@ class Buffer {
 
   T& operator()(int row, int col) { return v_[(size_t)row * cols_ + col]; }
   const T& operator()(int row, int col) const { return v_[(size_t)row * cols_ + col]; }
+  // linear index in storage (row-major) order, as Eigen's single-index access on the reference's Buffer
+  T& operator()(int i) { return v_[(size_t)i]; }
+  const T& operator()(int i) const { return v_[(size_t)i]; }
+  // buffer.hpp:534-544: note that the patch ROW follows the image X offset (patch(ix, iy) = pixel(x+ix-s/2, y+iy-s/2))
+  void getPatch(Buffer<uint8_t>& patch, int x, int y, int size) const {
+    patch.resize(size, size);
+    for (int ix = 0; ix < size; ix++)
+      for (int iy = 0; iy < size; iy++) patch(ix, iy) = getPixel(x + ix - (size / 2), y + iy - (size / 2));
+  }
   void setPixel(int x, int y, T color) { v_[(size_t)y * cols_ + x] = color; }
   T getPixel(int x, int y) const { return v_[(size_t)y * cols_ + x]; }
   void set(T color) { std::fill(v_.begin(), v_.end(), color); }
