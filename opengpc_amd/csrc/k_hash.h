@@ -121,13 +121,30 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
   __shared__ int s_cnt, s_last;
 
-  const int img = blockIdx.z;
+  // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2) in launch
+  // order, so launch-order neighbours never share an L2.  Remapped, XCD k works through its own
+  // contiguous eighth of the (x, y, image) tile list: the tiles that share a window apron (left /
+  // right, above / below) meet in one L2.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifndef HT_NO_XCD_REMAP
+  {
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    if ((nwg & 7u) == 0u) {
+      const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned logical = (flat & 7u) * (nwg >> 3) + (flat >> 3);
+      bx = logical % gridDim.x;
+      by = (logical / gridDim.x) % gridDim.y;
+      bz = logical / (gridDim.x * gridDim.y);
+    }
+  }
+#endif
+  const int img = bz;
   const long n = (long)W * H;
   const uint8_t* sm = smooth + (long)img * n;
   const uint8_t* gr = grad + (long)img * n;
   const uint8_t* cm = candmap ? candmap + (long)img * n : nullptr;
   uint32_t* out = codes + (long)img * n;
-  const int tx0 = blockIdx.x * HT_X;
+  const int tx0 = bx * HT_X;
   const int tid = threadIdx.x;
 
   if (tid == 0) { s_cnt = 0; s_last = -1; }
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     }
   };
 
-  const int tile0 = blockIdx.y * tpw;
+  const int tile0 = by * tpw;
   const int ntiles = (H + HT_Y - 1) / HT_Y;
   fetch(tile0 * HT_Y);
   int cnt = 0, last = -1;

@@ -70,21 +70,37 @@ template <bool NAIVE, int ROWS>
 __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
     uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
-  const int img = blockIdx.z;
+  // XCD-aware block order (see k_hash.h): launch-order neighbours sit on different XCDs; remapped, each
+  // XCD streams through its own contiguous eighth of the blocks, so the row above / below a strip that
+  // the neighbouring block also reads is found in the same L2.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifndef PP_NO_XCD_REMAP
+  {
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    if ((nwg & 7u) == 0u) {
+      const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned logical = (flat & 7u) * (nwg >> 3) + (flat >> 3);
+      bx = logical % gridDim.x;
+      by = (logical / gridDim.x) % gridDim.y;
+      bz = logical / (gridDim.x * gridDim.y);
+    }
+  }
+#endif
+  const int img = bz;
   const int pair = img / sides, side = img - pair * sides;
   const long n = (long)W * H;
   const uint8_t* raw = (side ? raw1 : raw0) + (long)pair * n;
   uint8_t* sm = smooth + (long)img * n;
   uint8_t* gr = grad + (long)img * n;
 
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (bx == 0 && by == 0 && threadIdx.x == 0) {
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_NCAND] = 0;
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_LASTROW] = -1;
   }
 
   const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;
-  const int x0 = (blockIdx.x * PP_TX + tx) * PP_PX;
-  const int ys = (blockIdx.y * PP_TY + ty) * ROWS;
+  const int x0 = (bx * PP_TX + tx) * PP_PX;
+  const int ys = (by * PP_TY + ty) * ROWS;
   if (x0 >= W || ys >= H) return;
 
   // last row the box filter writes: rows come in pairs from y=1 while y < H-3 (filter.hpp:307);
