@@ -1,0 +1,76 @@
+"""GPU parity on randomly drawn shapes, images, thresholds, forests, matcher modes and arithmetic
+variants (fixed seeds): whole path raw pair -> supports through the C ABI against the oracle, plus a
+ragged batch of the same shape.  Complements the hand-picked shapes of test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import sparsematch_settings
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import opengpc_amd as g
+    c = g.Context(0)
+    yield c
+    c.close()
+
+
+def draw_pair(rng, W, H):
+    kind = rng.integers(0, 4)
+    wide = W + 64
+    if kind == 0:    # fine noise
+        base = rng.integers(0, 256, (H, wide), dtype=np.uint8)
+    elif kind == 1:  # blocky texture + noise (many repeated codes)
+        k = int(rng.integers(2, 7))
+        base = (rng.integers(0, 256, (H // k + 1, wide // k + 1)).repeat(k, 0).repeat(k, 1)[:H, :wide] * 3 // 4
+                + rng.integers(0, 64, (H, wide))).astype(np.uint8)
+    elif kind == 2:  # smooth gradient + little noise (few candidates, long duplicate runs)
+        yy, xx = np.mgrid[0:H, 0:wide]
+        base = ((xx * 3 + yy * 2) % 256 + rng.integers(0, 8, (H, wide))).clip(0, 255).astype(np.uint8)
+    else:            # sparse dots on a flat background
+        base = np.full((H, wide), 60, np.uint8)
+        m = rng.random((H, wide)) < 0.03
+        base[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+    d = int(rng.integers(0, 33))
+    L = np.ascontiguousarray(base[:, 32:32 + W])
+    R = np.ascontiguousarray(base[:, 32 + d - 16:32 + d - 16 + W]) if d >= 16 else np.ascontiguousarray(base[:, 32 + d:32 + d + W])
+    if rng.random() < 0.3:  # a different right image altogether
+        R = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    return L, R
+
+
+# GPC_FUZZ_SEEDS=N widens the sweep for a one-off soak (the default 36 take ~2 s)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPC_FUZZ_SEEDS", "36"))))
+def test_random_configuration(ctx, oracle, forest_paths, seed):
+    import opengpc_amd as g
+    rng = np.random.default_rng(1000 + seed)
+    W = 16 * int(rng.integers(3, 140))            # 48 .. 2224
+    H = int(rng.integers(30, 150))
+    forest = "tau" if seed % 2 else "zero"
+    epipolar, hashtable = bool((seed >> 1) & 1), bool((seed >> 2) & 1)
+    naive = (seed % 9) == 4
+    thr = int(rng.choice([0, 3, 5, 10, 40, 181, 182, 255]))
+    disp_high = int(rng.choice([0, 7, 64, 128, 4000]))
+    vtol = int(rng.choice([-1, 0, 1, 3]))
+    L, R = draw_pair(rng, W, H)
+    rc, f = oracle.read_forest(forest_paths[forest], W, H)
+    ctx.set_arithmetic(naive)
+    try:
+        ctx.load_forest(forest_paths[forest], W, H)
+        want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(thr, disp_high, vtol, epipolar, hashtable, naive))
+        got, n, ncand, st = ctx.match_pair(L, R, g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1))
+        assert st == 0 and (nl, nr) == tuple(ncand), (W, H, forest, epipolar, hashtable, naive, thr)
+        assert n == len(want) and np.array_equal(got, want.astype(got.dtype)), (W, H, forest, epipolar, hashtable, naive, thr)
+        if seed % 3 == 0:  # the batch entry point on the same shape: pair 1 swaps the images
+            out, counts, nc, st = ctx.match_batch(np.stack([L, R]), np.stack([R, L]),
+                                                  g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1), max(n, 1) * 2 + W * H)
+            w2, l2, r2 = oracle.match_pair(R, L, f, sparsematch_settings(thr, disp_high, vtol, epipolar, hashtable, naive))
+            assert counts[0] == n and np.array_equal(out[0, :n], got)
+            assert counts[1] == len(w2) and np.array_equal(out[1, :counts[1]], w2.astype(got.dtype))
+            assert tuple(nc[1]) == (l2, r2)
+    finally:
+        ctx.set_arithmetic(False)
