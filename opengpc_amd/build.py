@@ -7,8 +7,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpc_hip.so")
 SOURCES = ["gpc_hip.hip"]
-HEADERS = ["gpc_device.h", "k_preprocess.h", "k_hash.h", "k_rowmatch.h", "k_rowjoin.h", "k_rowbucket.h", "k_global.h", "k_hashtable.h",
-           os.path.join("..", "..", "include", "gpc_hip.h")]
+
+
+def _headers():
+    """every header the translation unit can include: csrc/*.h and the C ABI"""
+    hs = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
+    return hs + [os.path.join("..", "..", "include", "gpc_hip.h")]
 
 
 def _hipcc():
@@ -22,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + _headers()]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -1098,9 +1098,14 @@ int gpc_hip_train_eval_level(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_spl
   HIPCHK(c, hipMemsetAsync(t->counts, 0, sizeof(int32_t) * (2 * nc + 1), c->stream));
   {
     Timed tm(c, KID_TRAIN_EVAL);
-    hipLaunchKernelGGL(gpc::k_ts_eval_level, dim3((unsigned)((t->np + TS_CHUNK - 1) / TS_CHUNK), ncand), dim3(TS_THREADS), 0,
+    // longest chunks that still leave >= 4096 workgroups (16 per CU); measured on 1 Mi triplets: 16 Ki-triplet
+    // chunks stream 1000 candidates at 7.3 TB/s (4 Ki: 6.4), but starve a 10-candidate launch
+    int iters = 64;
+    while (iters > 4 && ((t->np + (long)iters * TS_ITER - 1) / ((long)iters * TS_ITER)) * ncand < 4096) iters >>= 1;
+    const unsigned chunks = (unsigned)((t->np + (long)iters * TS_ITER - 1) / ((long)iters * TS_ITER));
+    hipLaunchKernelGGL(gpc::k_ts_eval_level, dim3(chunks, ncand), dim3(TS_THREADS), 0,
                        c->stream, (const uint8_t*)t->planes, (const uint8_t*)t->flags, t->np,
-                       (const gpc::GpcSplit*)t->d_cand, taulo, ntau, t->counts, t->counts + nc);
+                       (const gpc::GpcSplit*)t->d_cand, taulo, ntau, iters, t->counts, t->counts + nc);
   }
   hipLaunchKernelGGL(gpc::k_ts_tot, dim3((unsigned)((t->np / 4 + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0,
                      c->stream, (const uint8_t*)t->flags, t->np, t->counts + 2 * nc);

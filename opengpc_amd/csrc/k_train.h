@@ -21,7 +21,7 @@ namespace gpc {
 
 #define TS_PATCH 729
 #define TS_THREADS 256
-#define TS_CHUNK 4096     // triplets per workgroup of the evaluation kernels
+#define TS_ITER 1024      // triplets per workgroup and loop iteration of the evaluation kernel (4 per lane)
 #define TS_MAXTAU 64      // intercept values searched per candidate
 
 #define TSF_POS 1u
@@ -64,12 +64,14 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_begin(uint8_t* __restrict__ f
 
 __device__ __forceinline__ bool ts_dec(uint32_t a, uint32_t b, int tau) { return ((int)a - (int)b) < tau; }
 
-// ---- candidates of ONE level: tp / fp per (candidate, tau); blockIdx.y = candidate
+// ---- candidates of ONE level: tp / fp per (candidate, tau); blockIdx.y = candidate, blockIdx.x = chunk of
+// iters * 1024 triplets (the host picks iters: every workgroup ends with 2 * ntau global atomics, so
+// chunks are as long as the grid stays large enough to fill the device)
 // tp[c * ntau + k], fp[...] must be zero on entry.  The samples that count (tot) do not depend on
 // the candidate: k_ts_tot.  fn = tot - tp - fp.
 __global__ __launch_bounds__(TS_THREADS) void k_ts_eval_level(const uint8_t* __restrict__ planes,
                                                               const uint8_t* __restrict__ flags, long np,
-                                                              const GpcSplit* __restrict__ cand, int taulo, int ntau,
+                                                              const GpcSplit* __restrict__ cand, int taulo, int ntau, int iters,
                                                               int32_t* __restrict__ tp, int32_t* __restrict__ fp) {
   __shared__ int s_tp[TS_MAXTAU], s_fp[TS_MAXTAU];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_eval_level(const uint8_t* __r
   const uint8_t* pj = rj + (long)TS_PATCH * np;
   const uint8_t* ni = pi + (long)TS_PATCH * np;
   const uint8_t* nj = pj + (long)TS_PATCH * np;
-  const long c0 = (long)blockIdx.x * TS_CHUNK;
+  const long c0 = (long)blockIdx.x * iters * TS_ITER;  // a workgroup owns `iters` x 1024 consecutive triplets
 #pragma unroll 1
-  for (int it = 0; it < TS_CHUNK / (4 * TS_THREADS); ++it) {
+  for (int it = 0; it < iters; ++it) {
     const long t = c0 + ((long)it * TS_THREADS + tid) * 4;  // 4 triplets per lane (np is a multiple of 256... and of 4)
     uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, d0 = 0, d1 = 0, fl = 0x03030303u;
     if (t < np) {
@@ -109,20 +111,65 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_eval_level(const uint8_t* __r
       eq[b] = (f & TSF_EQ) != 0;
       ne[b] = (f & TSF_NE) != 0;
     }
-    for (int k = 0; k < ntau; ++k) {
-      const int tau = taulo + k;
+    if (ntau == 1) {  // zero optimizer: one intercept, the kernel is a pure byte stream
       int wtp = 0, wfp = 0;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const bool r = dr[b] < tau, p = dp[b] < tau, q = dn[b] < tau;  // Feature::getDecisions, Feature.hpp:101-109
+        const bool r = dr[b] < taulo, p = dp[b] < taulo, q = dn[b] < taulo;  // Feature::getDecisions, Feature.hpp:101-109
         const bool e = eq[b] && (r == p), d = ne[b] || (r != q);
-        wtp += __popcll(__ballot(counted[b] && e && d));               // ref == pos, ref != neg
-        wfp += __popcll(__ballot(counted[b] && !e && !d));             // ref != pos, ref == neg
+        wtp += __popcll(__ballot(counted[b] && e && d));                     // ref == pos, ref != neg
+        wfp += __popcll(__ballot(counted[b] && !e && !d));                   // ref != pos, ref == neg
       }
       if (lane == 0) {
-        if (wtp) atomicAdd(&s_tp[k], wtp);
-        if (wfp) atomicAdd(&s_fp[k], wfp);
+        if (wtp) atomicAdd(&s_tp[0], wtp);
+        if (wfp) atomicAdd(&s_fp[0], wfp);
       }
+    } else {
+      // All intercepts at once: a decision x(i) - x(j) < tau switches on at one intercept, so over the
+      // index k (tau = taulo + k) it is the bit mask ~0 << (diff - taulo + 1), and the class of a triplet
+      // is a few AND / XORs of three such masks.  A class mask changes at <= 4 places: instead of
+      // counting every k, each change is added to a difference array (a prefix sum at the end gives the
+      // count per k); the changes at k = 0 -- most of them -- are counted with a ballot, not an atomic.
+      const unsigned long long valid = (ntau >= 64) ? ~0ull : ((1ull << ntau) - 1ull);
+      int base_tp = 0, base_fp = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        auto step = [&](int diff) -> unsigned long long {
+          const int k = diff - taulo + 1;  // first index whose intercept exceeds diff
+          return k <= 0 ? ~0ull : (k >= 64 ? 0ull : (~0ull << k));
+        };
+        const unsigned long long rm = step(dr[b]), pm = step(dp[b]), qm = step(dn[b]);
+        const unsigned long long am = rm ^ pm, bm = rm ^ qm;  // ref != pos ; ref != neg on this level
+        unsigned long long tpm = 0ull, fpm = 0ull;
+        if (counted[b]) {
+          const unsigned long long e = eq[b] ? ~am : 0ull, d = ne[b] ? ~0ull : bm;
+          tpm = (e & d) & valid;
+          fpm = (~e & ~d) & valid;
+        }
+        base_tp += __popcll(__ballot((tpm & 1ull) != 0ull));
+        base_fp += __popcll(__ballot((fpm & 1ull) != 0ull));
+        // rising / falling edges at k >= 1
+        unsigned long long up = tpm & ~(tpm << 1) & ~1ull, dn_ = ~tpm & (tpm << 1) & valid;
+        while (up) { atomicAdd(&s_tp[__builtin_ctzll(up)], 1); up &= up - 1ull; }
+        while (dn_) { atomicAdd(&s_tp[__builtin_ctzll(dn_)], -1); dn_ &= dn_ - 1ull; }
+        up = fpm & ~(fpm << 1) & ~1ull;
+        dn_ = ~fpm & (fpm << 1) & valid;
+        while (up) { atomicAdd(&s_fp[__builtin_ctzll(up)], 1); up &= up - 1ull; }
+        while (dn_) { atomicAdd(&s_fp[__builtin_ctzll(dn_)], -1); dn_ &= dn_ - 1ull; }
+      }
+      if (lane == 0) {
+        if (base_tp) atomicAdd(&s_tp[0], base_tp);
+        if (base_fp) atomicAdd(&s_fp[0], base_fp);
+      }
+    }
+  }
+  __syncthreads();
+  if (ntau > 1 && tid < 2) {  // difference arrays -> counts per intercept
+    int* a = tid ? s_fp : s_tp;
+    int acc = 0;
+    for (int k = 0; k < ntau; ++k) {
+      acc += a[k];
+      a[k] = acc;
     }
   }
   __syncthreads();
