@@ -91,6 +91,7 @@ struct gpc_hip_train_set {
   int32_t* counts = nullptr;  // scratch: tp/fp per (candidate, tau) + tot
   gpc::GpcSplit* d_cand = nullptr;
   size_t counts_cap = 0, cand_cap = 0;
+  std::vector<int32_t> h_counts;  // host staging of the counters
 };
 
 namespace {
@@ -1110,10 +1111,13 @@ int gpc_hip_train_eval_level(gpc_hip_ctx* c, gpc_hip_train_set* t, const gpc_spl
   hipLaunchKernelGGL(gpc::k_ts_tot, dim3((unsigned)((t->np / 4 + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0,
                      c->stream, (const uint8_t*)t->flags, t->np, t->counts + 2 * nc);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(tp, t->counts, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(fp, t->counts + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(tot, t->counts + 2 * nc, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  // one copy back: [tp | fp | tot] are contiguous on the device
+  t->h_counts.resize(2 * nc + 1);
+  HIPCHK(c, hipMemcpyAsync(t->h_counts.data(), t->counts, sizeof(int32_t) * (2 * nc + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(tp, t->h_counts.data(), sizeof(int32_t) * nc);
+  memcpy(fp, t->h_counts.data() + nc, sizeof(int32_t) * nc);
+  *tot = t->h_counts[2 * nc];
   return GPC_OK;
 }
 
