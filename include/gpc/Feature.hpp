@@ -65,111 +65,82 @@ class Feature {
   // extension: reproducible sampling (tests)
   void seed(unsigned s) { rng = std::mt19937(s); }
 
-  // Feature.hpp:131-176: a random test inside the 7x7 (scale 2), 17x17 (1) or 27x27 (0) centre of the patch
+  // Feature.hpp:131-176.  A random test (i, j) whose two pixels lie in the centred side x side window of
+  // the 27x27 patch: scale 2 -> 7x7, 1 -> 17x17, 0 -> 27x27.  Draw order as in the reference (window cell
+  // of i, then of j, repeated until they differ; then the intercept), so a seeded generator yields the
+  // same sequence.  Patch index of an offset (dx, dy): (dx + 13) + 27 * (dy + 13), at every scale.
   void inline sampleHyperplane(int scale, params& p) {
-    if (scale == 2) {
-      p.i = p.j;
-      while (p.i == p.j) {
-        int i = randIJ7(rng);
-        int j = randIJ7(rng);
-        p.ix = i % 7 - 3;
-        p.iy = i / 7 - 3;
-        p.jx = j % 7 - 3;
-        p.jy = j / 7 - 3;
-        p.i = 280 + (p.ix + 3) + 27 * (p.iy + 3);
-        p.j = 280 + (p.jx + 3) + 27 * (p.jy + 3);
-      }
-    } else if (scale == 1) {
-      p.i = p.j;
-      while (p.i == p.j) {
-        int i = randIJ17(rng);
-        int j = randIJ17(rng);
-        p.ix = i % 17 - 8;
-        p.iy = i / 17 - 8;
-        p.jx = j % 17 - 8;
-        p.jy = j / 17 - 8;
-        p.i = 140 + (p.ix + 8) + 27 * (p.iy + 8);
-        p.j = 140 + (p.jx + 8) + 27 * (p.jy + 8);
-      }
-    } else if (scale == 0) {
-      p.i = p.j;
-      while (p.i == p.j) {
-        p.i = randIJ27(rng);
-        p.j = randIJ27(rng);
-        p.ix = p.i % 27 - 13;
-        p.iy = p.i / 27 - 13;
-        p.jx = p.j % 27 - 13;
-        p.jy = p.j / 27 - 13;
-        p.i = (p.ix + 13) + 27 * (p.iy + 13);
-        p.j = (p.jx + 13) + 27 * (p.jy + 13);
-      }
+    const int side = scale == 2 ? 7 : (scale == 1 ? 17 : 27);
+    if (scale >= 0 && scale <= 2) {
+      std::uniform_int_distribution<int>& cell = scale == 2 ? randIJ7 : (scale == 1 ? randIJ17 : randIJ27);
+      const int half = side / 2;
+      do {
+        const int ci = cell(rng);
+        const int cj = cell(rng);
+        p.ix = ci % side - half;
+        p.iy = ci / side - half;
+        p.jx = cj % side - half;
+        p.jy = cj / side - half;
+        p.i = patchIndex(p.ix, p.iy);
+        p.j = patchIndex(p.jx, p.jy);
+      } while (p.i == p.j);
     }
     p.tau = randTAU(rng);
   }
+  static int patchIndex(int dx, int dy) { return (dx + 13) + 27 * (dy + 13); }
 
-  // Feature.hpp:190-245: patches of the box-filtered images around the three keypoint lists.
-  // The 3x3 box + clearBoundary run on the GPU (the same preprocess kernel as inference).
+  // Feature.hpp:190-245: for every keypoint triple that lies more than 20 px inside the image, the 27x27
+  // patches of the smoothed left (ref) and right (pos, neg) image.  Smoothing = 3x3 box + clearBoundary,
+  // run on the GPU (the `smooth` output of preprocessImage).
   void extractAllTriplets(ndb::Buffer<uint8_t>& bwL, ndb::Buffer<uint8_t>& bwR, std::vector<ndb::Point>& ref,
                           std::vector<ndb::Point>& pos, std::vector<ndb::Point>& neg,
                           std::vector<GPCPatchTriplet>& triplets) {
-    ndb::Buffer<uint8_t> LL = smoothed(bwL), RR = smoothed(bwR);
-    auto f = [=](ndb::Point& kp) {
-      if (kp.x > 20 && kp.y > 20 && kp.x < bwL.cols() - 20 && kp.y < bwL.rows() - 20) return false;
-      else return true;
+    ndb::Buffer<uint8_t> smoothL = smoothed(bwL), smoothR = smoothed(bwR);
+    const int cols = bwL.cols(), rows = bwL.rows();
+    auto inside = [cols, rows](const ndb::Point& kp) {
+      return kp.x > 20 && kp.y > 20 && kp.x < cols - 20 && kp.y < rows - 20;
     };
-    for (std::vector<ndb::Point>::size_type i = 0; i != ref.size(); i++) {
-      if (!f(ref[i]) && !f(pos[i]) && !f(neg[i])) {
-        GPCPatchTriplet newPatch;
-        newPatch.ref.x = ref[i].x;
-        newPatch.ref.y = ref[i].y;
-        LL.getPatch(newPatch.ref.feature, ref[i].x, ref[i].y, 27);
-        newPatch.pos.x = pos[i].x;
-        newPatch.pos.y = pos[i].y;
-        RR.getPatch(newPatch.pos.feature, pos[i].x, pos[i].y, 27);
-        newPatch.neg.x = neg[i].x;
-        newPatch.neg.y = neg[i].y;
-        RR.getPatch(newPatch.neg.feature, neg[i].x, neg[i].y, 27);
-        triplets.push_back(std::move(newPatch));
-      }
+    auto cut = [](const ndb::Buffer<uint8_t>& img, const ndb::Point& at, GPCDescriptor& d) {
+      d.x = at.x;
+      d.y = at.y;
+      img.getPatch(d.feature, at.x, at.y, 27);
+    };
+    for (size_t k = 0; k < ref.size(); ++k) {
+      if (!(inside(ref[k]) && inside(pos[k]) && inside(neg[k]))) continue;
+      triplets.emplace_back();
+      cut(smoothL, ref[k], triplets.back().ref);
+      cut(smoothR, pos[k], triplets.back().pos);
+      cut(smoothR, neg[k], triplets.back().neg);
     }
   }
 
-  // Feature.hpp:254-263
+  // Feature.hpp:254-263: 3 x 729 bytes per triplet (ref, pos, neg), nothing else in the file
   void storeAllTriplets(std::vector<GPCPatchTriplet>& data, std::string path) {
-    ofstream fout;
-    fout.open(path, ios::binary | ios::out);
-    for (auto& triplet : data) {
-      fout.write((char*)triplet.ref.feature.data(), 27 * 27);
-      fout.write((char*)triplet.pos.feature.data(), 27 * 27);
-      fout.write((char*)triplet.neg.feature.data(), 27 * 27);
-    }
-    fout.close();
+    std::ofstream out(path, std::ios::binary);
+    for (const GPCPatchTriplet& t : data)
+      for (const GPCDescriptor* d : {&t.ref, &t.pos, &t.neg})
+        out.write(reinterpret_cast<const char*>(d->feature.data()), kPatchBytes);
   }
-  // Feature.hpp:272-297
+  // Feature.hpp:272-297: a file whose size is not a multiple of 3 x 729 is refused with the reference's message
   std::vector<GPCPatchTriplet> loadAllTriplets(std::string path) {
     std::vector<GPCPatchTriplet> data;
-    std::ifstream in(path, std::ifstream::ate | std::ifstream::binary);
-    uint32_t filesize = in.tellg();
-    if (filesize % ((27 * 27) * 3)) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    const uint32_t filesize = (uint32_t)in.tellg();  // 32 bits, like the reference
+    if (filesize % (3 * kPatchBytes)) {
       cout << "ERR: File is not a training set of this feature type" << endl;
       cout << "FS: " << filesize << endl;
       return data;
     }
-    int numSamples = filesize / ((27 * 27) * 3);
-    data.resize(numSamples);
-    ifstream fin;
-    fin.open(path, ios::binary | ios::in);
-    for (auto& datum : data) {
-      datum.ref.feature.resize(27, 27);
-      datum.pos.feature.resize(27, 27);
-      datum.neg.feature.resize(27, 27);
-      fin.read((char*)datum.ref.feature.data(), 27 * 27);
-      fin.read((char*)datum.pos.feature.data(), 27 * 27);
-      fin.read((char*)datum.neg.feature.data(), 27 * 27);
-    }
-    fin.close();
+    data.resize(filesize / (3 * kPatchBytes));
+    in.seekg(0);
+    for (GPCPatchTriplet& t : data)
+      for (GPCDescriptor* d : {&t.ref, &t.pos, &t.neg}) {
+        d->feature.resize(27, 27);
+        in.read(reinterpret_cast<char*>(d->feature.data()), kPatchBytes);
+      }
     return data;
   }
+  static constexpr int kPatchBytes = 27 * 27;
 
  private:
   void init(unsigned s) {

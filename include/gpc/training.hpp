@@ -57,55 +57,53 @@ struct ForestSettings {
 // training.hpp:91-159
 class Forest {
  private:
-  typedef gpc::training::Feature F;
-  typedef F::GPCPatchTriplet GPCTriplet_t;
+  typedef gpc::training::Feature::GPCPatchTriplet GPCTriplet_t;
   std::mt19937 rng;
   std::uniform_int_distribution<int> randSample;
 
+  // one line per fern ("<index> <s|m|l> <levels>") followed by one line per level
+  // ("<level> <ix> <iy> <jx> <jy> <tau>"): the format Forest::readForest parses (inference.hpp:404-446)
+  static void writeForest(std::vector<gpc::training::Fern>& ferns, const std::string& filename) {
+    std::ofstream file(filename, std::ios::out | std::ios::trunc);
+    file << ferns.size() << endl;
+    for (size_t f = 0; f < ferns.size(); ++f) {
+      const std::vector<gpc::training::Feature::params> levels = ferns[f].getParameters();
+      const int scale = ferns[f].getScale();  // 2: small, 1: medium, 0: large
+      file << f << " " << (scale == 2 ? "s" : (scale == 1 ? "m" : "l")) << " " << levels.size() << endl;
+      for (size_t l = 0; l < levels.size(); ++l)
+        file << l << " " << levels[l].ix << " " << levels[l].iy << " " << levels[l].jx << " " << levels[l].jy << " "
+             << levels[l].tau << endl;
+    }
+  }
+
  public:
   Forest() {}
+  // Every fern trains on its own bootstrap sample (with replacement) of sampleFraction * N triplets, drawn
+  // from the first sampleFraction * N triplets like the reference does (training.hpp:113-121).
   void trainAndExport(std::vector<GPCTriplet_t>& trainingSamples, gpc::training::ForestSettings forestSettings,
                       gpc::training::OptimizerSettings optSettings, std::string filename) {
-    std::chrono::high_resolution_clock::time_point t0, t1;
-    std::random_device rd2;
-    if (trainingSamples.size() == 0) {
+    if (trainingSamples.empty()) {
       cout << "ERR: Training set is empty. Aborting." << endl;
       return;
     }
-    rng = std::mt19937(rd2());
-    randSample =
-        std::uniform_int_distribution<int>(0, int(forestSettings.sampleFraction * trainingSamples.size()) - 1);
-    int fernIndex = 1;
-    for (auto& fern : forestSettings.ferns) {
-      std::vector<GPCTriplet_t> subSample;  // with replacement
-      for (int i = 0; i < int(forestSettings.sampleFraction * trainingSamples.size()); i++)
-        subSample.push_back(trainingSamples[randSample(rng)]);
-      cout << "Fern(" << fernIndex++ << "/" << forestSettings.ferns.size() << ") num samples:" << subSample.size();
-      cout << endl << std::string(90, '*') << endl;
-      t0 = std::chrono::high_resolution_clock::now();
-      fern.train(subSample, optSettings);
-      t1 = std::chrono::high_resolution_clock::now();
-      cout << "done in " << std::chrono::duration_cast<std::chrono::duration<double>>(t1 - t0).count() << " s"
-           << endl
-           << endl;
+    std::random_device seedSource;
+    rng = std::mt19937(seedSource());
+    const int perFern = int(forestSettings.sampleFraction * trainingSamples.size());
+    randSample = std::uniform_int_distribution<int>(0, perFern - 1);
+    const size_t total = forestSettings.ferns.size();
+    for (size_t f = 0; f < total; ++f) {
+      std::vector<GPCTriplet_t> bootstrap;
+      bootstrap.reserve(perFern > 0 ? perFern : 0);
+      for (int k = 0; k < perFern; ++k) bootstrap.push_back(trainingSamples[randSample(rng)]);
+      cout << "Fern(" << (f + 1) << "/" << total << ") num samples:" << bootstrap.size() << endl
+           << std::string(90, '*') << endl;
+      const auto started = std::chrono::high_resolution_clock::now();
+      forestSettings.ferns[f].train(bootstrap, optSettings);
+      const std::chrono::duration<double> took = std::chrono::high_resolution_clock::now() - started;
+      cout << "done in " << took.count() << " s" << endl << endl;
     }
     cout << "Exporting forest" << endl;
-    std::fstream file(filename, std::ofstream::out | std::ofstream::trunc);
-    file << forestSettings.ferns.size() << endl;
-    int f = 0;
-    for (auto& fern : forestSettings.ferns) {
-      std::vector<gpc::training::Feature::params> fparams = fern.getParameters();
-      int scale = fern.getScale();  // 2: small, 1: medium, 0: large
-      file << f << " " << ((scale == 2) ? "s" : ((scale == 1) ? "m" : "l")) << " " << fparams.size() << endl;
-      int i = 0;
-      for (auto& p : fparams) {
-        file << int(i) << " " << int(p.ix) << " " << int(p.iy) << " " << int(p.jx) << " " << int(p.jy) << " "
-             << int(p.tau) << endl;
-        i++;
-      }
-      f++;
-    }
-    file.close();
+    writeForest(forestSettings.ferns, filename);
   }
 };  // Forest
 }  // namespace training

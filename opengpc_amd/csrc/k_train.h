@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_eval_split(const uint8_t* __r
                                                               int n, long np, const GpcSplit* __restrict__ params,
                                                               int nparams, int32_t* __restrict__ counts) {
   __shared__ GpcSplit s_p[64];
-  if (threadIdx.x < nparams) s_p[threadIdx.x] = params[threadIdx.x];
+  if ((int)threadIdx.x < nparams) s_p[threadIdx.x] = params[threadIdx.x];
   __syncthreads();
   const long t = (long)blockIdx.x * TS_THREADS + threadIdx.x;
   const bool in = t < n;
