@@ -341,7 +341,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     }
     {
       Timed t(c, KID_GATHER_ROWS);
-      hipLaunchKernelGGL(gpc::k_gather_rows, grid, dim3(RM_THREADS), 0, c->stream,
+      hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS, npairs), dim3(RM_THREADS), 0, c->stream,
                          (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
                          cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
       HIPCHK(c, hipGetLastError());

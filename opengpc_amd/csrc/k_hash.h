@@ -261,7 +261,11 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   if (__ballot(any)) {  // wave-uniform: skip segments with nothing to hash
 #endif
     const int T = f.num_tests;
-    const int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
+    int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
+    // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
+    // becomes an immediate that no longer fits the 8-bit dword offsets of ds_read2_b32, and every pair of
+    // row reads then needs its own address add (6 adds per test instead of 2)
+    asm volatile("" : "+v"(lanebase));
     uint32_t p0[RPW], p1[RPW], p2[RPW], p3[RPW], p8[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) p0[r] = p1[r] = p2[r] = p3[r] = p8[r] = ~0u;  // "ge" planes: all-ones = no bit

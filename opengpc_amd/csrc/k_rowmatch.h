@@ -198,38 +198,47 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 
 // Expands the staged rows into the caller's array, rows in ascending order.
 // mode 0: gpc_support {x, y, float(xL-xR)}; mode 1: gpc_correspondence {xL, y, xR, y}
-// grid: (H - 26, npairs)
+// grid: (ceil((H - 26) / GR_ROWS), npairs).  A workgroup expands GR_ROWS consecutive rows: one block-wide
+// sum of the earlier rows' counts for the first of them, a running offset for the rest (one row per
+// workgroup spent most of its time on that sum: 105 k workgroups of ~2 us each at 256 pairs).
+#ifndef GR_ROWS
+#define GR_ROWS 4   // measured at 256 pairs: 1 row per workgroup 226 us, 2 -> 189, 4 -> 161, 8 -> 170, 16 -> 178
+#endif
 __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
     const uint32_t* __restrict__ staged, const int32_t* __restrict__ rowcnt, int W, int H, int mode,
     void* __restrict__ out, int cap, int32_t* __restrict__ counts, const int32_t* __restrict__ img_stats,
     int32_t* __restrict__ ncand) {
-  const int y = GPC_R + blockIdx.x, pair = blockIdx.y;
+  const int y0 = GPC_R + blockIdx.x * GR_ROWS, pair = blockIdx.y;
   const int32_t* rc = rowcnt + (long)pair * H;
-  const int off = block_prefix_rows(rc, GPC_R, y);
-  const int cnt = rc[y];
-  const uint32_t* src = staged + ((long)pair * H + y) * W;
-  if (mode == 0) {
-    uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pair * cap * 3;
-    for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
-      const int pos = off + i;
-      if (pos >= cap) break;
-      const uint32_t v = src[i];
-      const int xl = v & 0xFFFF, xr = v >> 16;
-      o[pos * 3 + 0] = xl;
-      o[pos * 3 + 1] = y;
-      o[pos * 3 + 2] = __float_as_uint((float)(xl - xr));
+  int off = block_prefix_rows(rc, GPC_R, y0);
+  const int yend = min(y0 + GR_ROWS, H - GPC_R);
+  for (int y = y0; y < yend; ++y) {
+    const int cnt = rc[y];
+    const uint32_t* src = staged + ((long)pair * H + y) * W;
+    if (mode == 0) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pair * cap * 3;
+      for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
+        const int pos = off + i;
+        if (pos >= cap) break;
+        const uint32_t v = src[i];
+        const int xl = v & 0xFFFF, xr = v >> 16;
+        o[pos * 3 + 0] = xl;
+        o[pos * 3 + 1] = y;
+        o[pos * 3 + 2] = __float_as_uint((float)(xl - xr));
+      }
+    } else {
+      int4* o = reinterpret_cast<int4*>(out) + (long)pair * cap;
+      for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
+        const int pos = off + i;
+        if (pos >= cap) break;
+        const uint32_t v = src[i];
+        o[pos] = make_int4(v & 0xFFFF, y, v >> 16, y);
+      }
     }
-  } else {
-    int4* o = reinterpret_cast<int4*>(out) + (long)pair * cap;
-    for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
-      const int pos = off + i;
-      if (pos >= cap) break;
-      const uint32_t v = src[i];
-      o[pos] = make_int4(v & 0xFFFF, y, v >> 16, y);
-    }
+    off += cnt;
   }
-  if (y == H - GPC_R - 1 && threadIdx.x == 0) {
-    counts[pair] = off + cnt;
+  if (yend == H - GPC_R && threadIdx.x == 0) {
+    counts[pair] = off;
     if (ncand) {
       ncand[pair * 2 + 0] = img_stats[(pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
       ncand[pair * 2 + 1] = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
