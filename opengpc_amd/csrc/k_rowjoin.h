@@ -12,8 +12,10 @@
 //   1. the left row's codes are inserted into an ordered open-addressing table with
 //      ds_max_rtn (Amble-Knuth ordered linear probing; a wave-level LDS CAS measured ~72
 //      cycles of LDS pipe on MI355X, a returning ds_max ~8);
-//   2. both rows look their code up (plain reads) and add (1<<16)+x into the slot's left /
-//      right accumulator (ds_add): count and, while the count is 1, the record's x;
+//   2. both rows look their code up (plain reads) and count themselves in the slot's packed
+//      counter word (ds_add of 1 / 1 << 16: left count in the low half, right count in the high
+//      half); a right record also leaves its x in a 16-bit cell of the slot (plain store: if the
+//      right count ends up 1 there was one writer, otherwise the value is not used);
 //   3. every left record reads its slot: match iff both counts are 1 (+ disparity filter);
 //   4. output position = rank of the code among the row's matches, by COUNTING on the top
 //      bits of the code: one returning ds_add per match, an exclusive scan over 256*SPT bucket
@@ -64,9 +66,10 @@ __device__ __forceinline__ uint32_t rj_hash(uint32_t code, int shift) { return (
 // that key on to the next slot.  Within one insert phase this converges to the unique ordered
 // table whatever the interleaving; lookups (after the barrier) are read-only and stop at the
 // first slot holding a smaller key.  Stored key = code + 1 (0 = empty slot).
-// Only LEFT codes are inserted; right records merely look their code up.  Per slot two
-// accumulators collect (count << 16) + x with non-returning ds_add: while count == 1 the low
-// half is that record's x, and a count field can never read 1 for count >= 2.
+// Only LEFT codes are inserted; right records merely look their code up.  A slot costs 10 bytes
+// (key, two 16-bit counts in one word, 16-bit x of a right record): 20 KiB per 1024-px row, so
+// SEVEN workgroups share a CU (at 12 bytes -- x summed into two 32-bit accumulators -- six did:
+// 686 -> 628 us per 256 pairs).  Counts cannot overflow their halves (a row has < 65536 records).
 
 // insert SPT keys per thread (0 = none); the first probes of all slots are issued together
 template <int SPT>
@@ -108,11 +111,11 @@ __device__ __forceinline__ uint32_t rj_find(const uint32_t* __restrict__ t_key, 
 // rowcnt:  [npairs][H]
 // grid: (H - 26, npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
 //       S >= max(2*(W-26), NB)   (only left codes are inserted: load factor <= 0.5)
-// dynamic LDS: 12*(S+1) bytes  (24 KiB for W = 1024: 6 workgroups per CU)
+// dynamic LDS: 10*(S+1) + 2 bytes  (20 KiB for W = 1024: 7 workgroups per CU, 72 VGPRs)
 // Wide rows use more threads per row instead of more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
 template <int SPT, int NT>
-__global__ __launch_bounds__(NT) void k_row_join(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 7 : 1, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s, int rpw) {
@@ -124,10 +127,10 @@ __global__ __launch_bounds__(NT) void k_row_join(
   __shared__ uint32_t s_w[NT / 64];
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
-  uint32_t* t_wl = rj_lds + (S + 1);      // [S]   left  accumulators (count << 16) + x
-  uint32_t* t_wr = rj_lds + 2 * (S + 1);  // [S]   right accumulators
-  uint32_t* r_cnt = t_wl;                 // [NB+1] bucket counters -> starts   (reuses t_wl after step 3)
-  uint32_t* r_key = t_wr;                 // [NB]   matched codes, bucket-contiguous (reuses t_wr)
+  uint32_t* t_cnt = rj_lds + (S + 1);     // [S]   records per slot: left count in the low half, right count in the high half
+  uint16_t* t_x = reinterpret_cast<uint16_t*>(rj_lds + 2 * (S + 1));  // [S] x of a right record of the slot (THE one if the count is 1)
+  uint32_t* r_cnt = t_key;                // [NB+1] bucket counters -> starts   (reuses t_key, dead after step 2)
+  uint32_t* r_key = t_cnt;                // [NB]   matched codes, bucket-contiguous (reuses t_cnt, dead after step 3)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int pair = blockIdx.y;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NT) void k_row_join(
     if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
-      for (int i = tid; i < (3 * (S + 1) + 3) / 4; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid; i < (10 * (S + 1) + 2 + 15) / 16; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid == 0) {
       s_max_r = -1;
@@ -213,11 +216,14 @@ __global__ __launch_bounds__(NT) void k_row_join(
       hl[j] = 0u;
       if (kl[j]) {
         hl[j] = rj_find(t_key, kl[j], f0l[j], h0l[j], smask);  // a left code is always found
-        atomicAdd(&t_wl[hl[j]], (1u << 16) + x);
+        atomicAdd(&t_cnt[hl[j]], 1u);
       }
       if (kr[j]) {
         const uint32_t hr = rj_find(t_key, kr[j], f0r[j], h0r[j], smask);
-        if (hr != 0xFFFFFFFFu) atomicAdd(&t_wr[hr], (1u << 16) + x);
+        if (hr != 0xFFFFFFFFu) {
+          atomicAdd(&t_cnt[hr], 1u << 16);
+          t_x[hr] = (uint16_t)x;  // plain store: several writers only when the count is not 1, and then x is not used
+        }
       }
     }
   }
@@ -237,7 +243,8 @@ __global__ __launch_bounds__(NT) void k_row_join(
   __syncthreads();
   RJ_STAMP(2);
 
-  // ---- 3. decide every left candidate
+  // ---- 3. decide every left candidate; the key table is dead already: it becomes the rank counters
+  for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
   bool ok[SPT];
   uint32_t xr[SPT];
 #pragma unroll
@@ -245,10 +252,10 @@ __global__ __launch_bounds__(NT) void k_row_join(
     ok[j] = false;
     xr[j] = 0u;
     if (kl[j]) {
-      const uint32_t wl = t_wl[hl[j]], wr = t_wr[hl[j]];
+      const uint32_t cn = t_cnt[hl[j]];
       const bool tail = tail_row && kl[j] == tail_key;
-      bool good = ((wl >> 16) == 1u) && (tail ? (s_tail_cnt == 2) : ((wr >> 16) == 1u));
-      xr[j] = tail ? s_tail_minx : (wr & 0xFFFFu);
+      bool good = ((cn & 0xFFFFu) == 1u) && (tail ? (s_tail_cnt == 2) : ((cn >> 16) == 1u));
+      xr[j] = tail ? s_tail_minx : (uint32_t)t_x[hl[j]];
       if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
       ok[j] = good;
     }
@@ -257,8 +264,6 @@ __global__ __launch_bounds__(NT) void k_row_join(
   RJ_STAMP(3);
 
   // ---- 4. output position = rank of the code among the row's matches (counting rank)
-  for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
-  __syncthreads();
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_row_join(
   RJ_STAMP(6);
   RJ_STAMP_FLUSH();
   if (tid == 0) rowcnt[rowbase] = (int32_t)r_cnt[NB];
-  __syncthreads();  // the table is cleared again for the next row
+  if (ri + 1 < rpw && y + 1 < H - GPC_R) __syncthreads();  // the table is cleared again for the next row
   }  // rows of this workgroup
 }
 
