@@ -277,7 +277,10 @@ def main():
             "pipeline_alg_bytes_per_pair": a_pair,
             "pipeline_frac": round(a_pair * pairs_per_step * args.steps / t_max / 1e9 / HBM_PEAK_GBS, 4),
             "launches_timed": dom_n,
-            "note": "duration = HIP events around every %s launch inside the timed region (steps of %d "
+            "note": "achieved = SURVEY 8d's ALGORITHMIC bytes of a sort-based matcher (36 B per candidate) / launch "
+                    "duration: the join keeps that sort on-chip (LDS), so it can exceed what HBM could stream and its "
+                    "measured HBM traffic (`traffic`) is ~5x smaller. "
+                    "Duration = HIP events around every %s launch inside the timed region (steps of %d "
                     "alternating streams may overlap it with the next step's HBM-bound kernels); `kernels` = "
                     "per-kernel split of 5 extra serial steps; largest there: %s" % (dom_name, P, serial_dom),
             "kernels": kinfo,
