@@ -299,7 +299,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
                     // S >= NT*SPT because the rank phase reuses the accumulators as bucket counters
     while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < jnt * jspt) ++log2s;
-    const size_t join_lds = ((size_t)10 * ((1u << log2s) + 1) + 2 + 15) / 16 * 16;  // keys + packed counts + 16-bit x
+    const size_t join_lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
     const bool use_join = c->row_kernel == 0 && jspt * jnt >= W && join_lds <= 150 * 1024;
     const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
     const bool use_bucket = c->row_kernel == 1 && spt <= 16;

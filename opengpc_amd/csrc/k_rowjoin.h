@@ -12,11 +12,12 @@
 //   1. the left row's codes are inserted into an ordered open-addressing table with
 //      ds_max_rtn (Amble-Knuth ordered linear probing; a wave-level LDS CAS measured ~72
 //      cycles of LDS pipe on MI355X, a returning ds_max ~8);
-//   2. both rows look their code up (plain reads) and count themselves in the slot's packed
-//      counter word (ds_add of 1 / 1 << 16: left count in the low half, right count in the high
-//      half); a right record also leaves its x in a 16-bit cell of the slot (plain store: if the
-//      right count ends up 1 there was one writer, otherwise the value is not used);
-//   3. every left record reads its slot: match iff both counts are 1 (+ disparity filter);
+//   2. both rows look their code up (plain reads) and mark the slot: a returning ds_or sets the
+//      side's SEEN flag, and a record that finds it already set adds the side's DUP flag; a right
+//      record also leaves its x in the low half of the slot's word (plain 16-bit store: if the
+//      right code is unique there was one writer, otherwise the value is not used);
+//   3. every left record reads its slot: match iff neither side is DUP and the right side was
+//      SEEN (+ disparity filter);
 //   4. output position = rank of the code among the row's matches, by COUNTING on the top
 //      bits of the code: one returning ds_add per match, an exclusive scan over 256*SPT bucket
 //      counters (DPP wave scan), and a look at the < 1 other matches sharing the bucket.
@@ -28,6 +29,11 @@ namespace gpc {
 
 #define RJ_THREADS 256
 #define RJ_EMPTY 0xFFFFFFFFu
+// flags of a table slot (high half of its word; the low half holds a right record's x)
+#define RJ_LSEEN 0x00010000u
+#define RJ_LDUP 0x00020000u
+#define RJ_RSEEN 0x00040000u
+#define RJ_RDUP 0x00080000u
 
 // Diagnostic build only (-DGPC_STAMPS, tools/stamp_profile.py): s_memtime at phase boundaries,
 // summed per phase into a debug buffer nothing else reads.  No stamp executes in the product build.
@@ -66,10 +72,11 @@ __device__ __forceinline__ uint32_t rj_hash(uint32_t code, int shift) { return (
 // that key on to the next slot.  Within one insert phase this converges to the unique ordered
 // table whatever the interleaving; lookups (after the barrier) are read-only and stop at the
 // first slot holding a smaller key.  Stored key = code + 1 (0 = empty slot).
-// Only LEFT codes are inserted; right records merely look their code up.  A slot costs 10 bytes
-// (key, two 16-bit counts in one word, 16-bit x of a right record): 20 KiB per 1024-px row, so
-// SEVEN workgroups share a CU (at 12 bytes -- x summed into two 32-bit accumulators -- six did:
-// 686 -> 628 us per 256 pairs).  Counts cannot overflow their halves (a row has < 65536 records).
+// Only LEFT codes are inserted; right records merely look their code up.  A slot costs 8 bytes
+// (key + one word of flags and x): 16 KiB per 1024-px row and 64 VGPRs, so EIGHT workgroups = 32
+// waves share a CU.  Earlier layouts, per 256 pairs: 12 bytes (count << 16 + x summed into two
+// 32-bit accumulators per slot), six workgroups: 686 us; 10 bytes (two 16-bit counts + 16-bit x),
+// seven: 628 us; this one: 595 us.
 
 // insert SPT keys per thread (0 = none); the first probes of all slots are issued together
 template <int SPT>
@@ -111,11 +118,11 @@ __device__ __forceinline__ uint32_t rj_find(const uint32_t* __restrict__ t_key, 
 // rowcnt:  [npairs][H]
 // grid: (H - 26, npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
 //       S >= max(2*(W-26), NB)   (only left codes are inserted: load factor <= 0.5)
-// dynamic LDS: 10*(S+1) + 2 bytes  (20 KiB for W = 1024: 7 workgroups per CU, 72 VGPRs)
+// dynamic LDS: 8*(S+1) bytes  (16 KiB for W = 1024: 8 workgroups per CU = 32 waves, 64 VGPRs)
 // Wide rows use more threads per row instead of more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
 template <int SPT, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 7 : 1, 8))) void k_row_join(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 8 : 1, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s, int rpw) {
@@ -127,10 +134,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 
   __shared__ uint32_t s_w[NT / 64];
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
-  uint32_t* t_cnt = rj_lds + (S + 1);     // [S]   records per slot: left count in the low half, right count in the high half
-  uint16_t* t_x = reinterpret_cast<uint16_t*>(rj_lds + 2 * (S + 1));  // [S] x of a right record of the slot (THE one if the count is 1)
+  uint32_t* t_w = rj_lds + (S + 1);       // [S]   per slot: seen / duplicate flags of either side (RJ_*), x of a right record in the low half
   uint32_t* r_cnt = t_key;                // [NB+1] bucket counters -> starts   (reuses t_key, dead after step 2)
-  uint32_t* r_key = t_cnt;                // [NB]   matched codes, bucket-contiguous (reuses t_cnt, dead after step 3)
+  uint32_t* r_key = t_w;                  // [NB]   matched codes, bucket-contiguous (reuses t_w, dead after step 3)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int pair = blockIdx.y;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 
     if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
-      for (int i = tid; i < (10 * (S + 1) + 2 + 15) / 16; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid; i < (8 * (S + 1) + 15) / 16; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid == 0) {
       s_max_r = -1;
@@ -216,13 +222,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 
       hl[j] = 0u;
       if (kl[j]) {
         hl[j] = rj_find(t_key, kl[j], f0l[j], h0l[j], smask);  // a left code is always found
-        atomicAdd(&t_cnt[hl[j]], 1u);
+        if (atomicOr(&t_w[hl[j]], RJ_LSEEN) & RJ_LSEEN) atomicOr(&t_w[hl[j]], RJ_LDUP);  // a second left record of this code
       }
       if (kr[j]) {
         const uint32_t hr = rj_find(t_key, kr[j], f0r[j], h0r[j], smask);
         if (hr != 0xFFFFFFFFu) {
-          atomicAdd(&t_cnt[hr], 1u << 16);
-          t_x[hr] = (uint16_t)x;  // plain store: several writers only when the count is not 1, and then x is not used
+          if (atomicOr(&t_w[hr], RJ_RSEEN) & RJ_RSEEN) atomicOr(&t_w[hr], RJ_RDUP);
+          // plain 16-bit store beside the flags: several writers only when the code is not unique, and then x is not used
+          reinterpret_cast<uint16_t*>(t_w)[2 * hr] = (uint16_t)x;
         }
       }
     }
@@ -252,10 +259,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 
     ok[j] = false;
     xr[j] = 0u;
     if (kl[j]) {
-      const uint32_t cn = t_cnt[hl[j]];
+      const uint32_t w = t_w[hl[j]];
       const bool tail = tail_row && kl[j] == tail_key;
-      bool good = ((cn & 0xFFFFu) == 1u) && (tail ? (s_tail_cnt == 2) : ((cn >> 16) == 1u));
-      xr[j] = tail ? s_tail_minx : (uint32_t)t_x[hl[j]];
+      bool good = !(w & RJ_LDUP) && (tail ? (s_tail_cnt == 2) : ((w & (RJ_RSEEN | RJ_RDUP)) == RJ_RSEEN));
+      xr[j] = tail ? s_tail_minx : (w & 0xFFFFu);
       if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
       ok[j] = good;
     }
