@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t rj_find(const uint32_t* __restrict__ t_key, 
 // Wide rows use more threads per row instead of more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
 template <int SPT, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 8 : 1, 8))) void k_row_join(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s, int rpw) {
