@@ -341,9 +341,10 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     }
     {
       Timed t(c, KID_GATHER_ROWS);
-      hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS, npairs), dim3(RM_THREADS), 0, c->stream,
+      const int gr = ((long)((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS) * npairs >= 2048) ? GR_ROWS : 1;
+      hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + gr - 1) / gr, npairs), dim3(RM_THREADS), 0, c->stream,
                          (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
-                         cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
+                         cap, d_counts, (const int32_t*)c->stats.p, d_ncand, gr);
       HIPCHK(c, hipGetLastError());
     }
     return GPC_OK;

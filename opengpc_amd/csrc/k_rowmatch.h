@@ -198,7 +198,8 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 
 // Expands the staged rows into the caller's array, rows in ascending order.
 // mode 0: gpc_support {x, y, float(xL-xR)}; mode 1: gpc_correspondence {xL, y, xR, y}
-// grid: (ceil((H - 26) / GR_ROWS), npairs).  A workgroup expands GR_ROWS consecutive rows: one block-wide
+// grid: (ceil((H - 26) / rows_per_wg), npairs).  A workgroup expands rows_per_wg (GR_ROWS; 1 for launches too
+// small to fill the device otherwise) consecutive rows: one block-wide
 // sum of the earlier rows' counts for the first of them, a running offset for the rest (one row per
 // workgroup spent most of its time on that sum: 105 k workgroups of ~2 us each at 256 pairs).
 #ifndef GR_ROWS
@@ -207,11 +208,11 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
     const uint32_t* __restrict__ staged, const int32_t* __restrict__ rowcnt, int W, int H, int mode,
     void* __restrict__ out, int cap, int32_t* __restrict__ counts, const int32_t* __restrict__ img_stats,
-    int32_t* __restrict__ ncand) {
-  const int y0 = GPC_R + blockIdx.x * GR_ROWS, pair = blockIdx.y;
+    int32_t* __restrict__ ncand, int rows_per_wg) {
+  const int y0 = GPC_R + blockIdx.x * rows_per_wg, pair = blockIdx.y;
   const int32_t* rc = rowcnt + (long)pair * H;
   int off = block_prefix_rows(rc, GPC_R, y0);
-  const int yend = min(y0 + GR_ROWS, H - GPC_R);
+  const int yend = min(y0 + rows_per_wg, H - GPC_R);
   for (int y = y0; y < yend; ++y) {
     const int cnt = rc[y];
     const uint32_t* src = staged + ((long)pair * H + y) * W;
