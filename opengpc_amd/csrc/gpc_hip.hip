@@ -56,6 +56,9 @@ struct gpc_hip_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // gpc_hip_match_batch: upload / download streams and the events that chain a chunk's stages
+  hipStream_t s_in = nullptr, s_out = nullptr, s_cnt = nullptr;
+  hipEvent_t e_in[2] = {nullptr, nullptr}, e_comp[2] = {nullptr, nullptr}, e_cnt[2] = {nullptr, nullptr};
   char err[256] = {0};
 
   bool naive = false;  // gpc_hip_set_arithmetic: the reference's SSE=OFF (*Naive) arithmetic
@@ -590,6 +593,16 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto& s : c->free_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  if (c->s_in) {
+    (void)hipStreamDestroy(c->s_in);
+    (void)hipStreamDestroy(c->s_out);
+    (void)hipStreamDestroy(c->s_cnt);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventDestroy(c->e_in[i]);
+      (void)hipEventDestroy(c->e_comp[i]);
+      (void)hipEventDestroy(c->e_cnt[i]);
+    }
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GPC_OK;
@@ -885,34 +898,72 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   return GPC_OK;
 }
 
+// Host buffers in, supports out.  The batch goes through the device in chunks: while chunk k is matched
+// on the context's stream, chunk k+1 is uploaded on a second stream and the supports of chunk k-1 go
+// back on a third (PCIe is full duplex), so the call costs about what the longer direction of the link
+// costs -- the results' way back -- instead of upload + kernels + download one after the other.
+// The only host waits are for a chunk's counts, which say how many supports of each pair to fetch.
 int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
                         const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
   if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
+  CHK(check_settings(s));
   CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)W * H;
-  CHK(ensure(c, c->raw, 2 * n * npairs));
+  const int chunk = npairs >= 8 ? (npairs >= 32 ? 8 : npairs / 4) : npairs;  // >= 4 chunks once there are 8 pairs
+  const int nch = (npairs + chunk - 1) / chunk;
+  CHK(ensure(c, c->raw, 2 * 2 * n * chunk));  // two slots x two sides
   CHK(ensure(c, c->out, sizeof(gpc_support) * (size_t)cap * npairs));
   CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
   CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
-  uint8_t* d_l = (uint8_t*)c->raw.p;
-  uint8_t* d_r = d_l + n * npairs;
-  HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
-  CHK(gpc_hip_match_batch_device(c, d_l, d_r, W, H, npairs, s, (gpc_support*)c->out.p, cap,
-                                 (int32_t*)c->counts.p, (int32_t*)c->ncand.p));
-  HIPCHK(c, hipMemcpyAsync(counts, c->counts.p, sizeof(int32_t) * npairs, hipMemcpyDeviceToHost, c->stream));
-  if (ncand)
-    HIPCHK(c, hipMemcpyAsync(ncand, c->ncand.p, sizeof(int32_t) * 2 * npairs, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  int status = GPC_OK;
-  for (int p = 0; p < npairs; ++p) {
-    const int ncopy = counts[p] < cap ? counts[p] : cap;
-    if (counts[p] > cap) status = GPC_E_CAPACITY;
-    if (ncopy > 0)
-      HIPCHK(c, hipMemcpyAsync(out + (size_t)p * cap, (gpc_support*)c->out.p + (size_t)p * cap,
-                               sizeof(gpc_support) * (size_t)ncopy, hipMemcpyDeviceToHost, c->stream));
+  if (!c->s_in) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_cnt, hipStreamNonBlocking));  // the counts: never queued behind bulk copies
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(c, hipEventCreateWithFlags(&c->e_in[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->e_comp[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->e_cnt[i], hipEventDisableTiming));
+    }
   }
+  int status = GPC_OK;
+  // fetch the supports of chunk k (its counts are on their way: wait for them, then one copy per pair)
+  auto collect = [&](int k) -> int {
+    const int p0 = k * chunk, pc = (p0 + chunk <= npairs) ? chunk : npairs - p0;
+    HIPCHK(c, hipEventSynchronize(c->e_cnt[k & 1]));
+    for (int p = p0; p < p0 + pc; ++p) {
+      const int ncopy = counts[p] < cap ? counts[p] : cap;
+      if (counts[p] > cap) status = GPC_E_CAPACITY;
+      if (ncopy > 0)
+        HIPCHK(c, hipMemcpyAsync(out + (size_t)p * cap, (gpc_support*)c->out.p + (size_t)p * cap,
+                                 sizeof(gpc_support) * (size_t)ncopy, hipMemcpyDeviceToHost, c->s_out));
+    }
+    return GPC_OK;
+  };
+  for (int k = 0; k < nch; ++k) {
+    const int slot = k & 1, p0 = k * chunk, pc = (p0 + chunk <= npairs) ? chunk : npairs - p0;
+    uint8_t* d_l = (uint8_t*)c->raw.p + (size_t)slot * 2 * n * chunk;
+    uint8_t* d_r = d_l + n * chunk;
+    if (k >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->e_comp[slot], 0));  // chunk k-2 has read this slot
+    HIPCHK(c, hipMemcpyAsync(d_l, rawL + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipMemcpyAsync(d_r, rawR + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipEventRecord(c->e_in[slot], c->s_in));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_in[slot], 0));
+    CHK(gpc_hip_match_batch_device(c, d_l, d_r, W, H, pc, s, (gpc_support*)c->out.p + (size_t)p0 * cap, cap,
+                                   (int32_t*)c->counts.p + p0, (int32_t*)c->ncand.p + 2 * p0));
+    HIPCHK(c, hipEventRecord(c->e_comp[slot], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->s_cnt, c->e_comp[slot], 0));
+    HIPCHK(c, hipMemcpyAsync(counts + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
+    if (ncand)
+      HIPCHK(c, hipMemcpyAsync(ncand + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc,
+                               hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipEventRecord(c->e_cnt[slot], c->s_cnt));
+    if (k >= 1) CHK(collect(k - 1));
+  }
+  CHK(collect(nch - 1));
+  HIPCHK(c, hipStreamSynchronize(c->s_out));
+  HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return status;
 }

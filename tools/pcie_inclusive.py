@@ -20,8 +20,10 @@ def main():
     ctx.load_forest(os.path.join(ROOT, "forests", "defaultZeroForest.txt"), W, H)
     s = g.Settings.sparsematch()
     res = []
-    for B in (1, 32):
+    for B in (1, 32, 256):
         for pinned in (False, True):
+            if B == 256 and not pinned:
+                continue
             L, R = synth_batch(W, H, list(range(B)))
             cap = 300000
             out = None
