@@ -169,12 +169,14 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
       const int c = tid + i * HT_THREADS;
       const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
       // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
-      const long k = (long)(ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
+      // an image has at most 2^30 pixels (check_dims): 32-bit offsets; one unsigned compare per range check
+      const int k = (ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
       pv[i] = make_uint4(0, 0, 0, 0);
       pn[i] = 0;
       if (c < NCHUNK) {
-        if (k >= 0 && k + 16 <= n) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
-        if (q + 1 < HT_STRIDE / 16 && k + 16 >= 0 && k + 20 <= n) pn[i] = *reinterpret_cast<const uint32_t*>(sm + k + 16);
+        if ((unsigned)k <= (unsigned)((int)n - 16)) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
+        if (q + 1 < HT_STRIDE / 16 && (unsigned)(k + 16) <= (unsigned)((int)n - 4))
+          pn[i] = *reinterpret_cast<const uint32_t*>(sm + k + 16);
       }
     }
   };
