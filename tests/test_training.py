@@ -233,3 +233,38 @@ def test_gpu_level_pieces_and_errors(ctx, oracle):
     with pytest.raises(ValueError):
         ctx.train_set(np.zeros((4, 3, 700), np.uint8))
     ts.close()
+
+
+@pytest.mark.gpu
+def test_gpu_training_limits(ctx, oracle):
+    """The edges of the C ABI: 64 levels (the reference's code words have 64 bits), 64 intercepts per
+    candidate, first / last patch byte, intercepts beyond the byte range, a set that is not a multiple
+    of the 4 triplets a lane handles."""
+    import opengpc_amd as g
+    n = 1023
+    t = make_triplets(n, 41, noise=40)
+    ts = ctx.train_set(t)
+    # 64 levels, one candidate each, a single intercept
+    cand = make_cands(64, 42)
+    cand["i"][:2], cand["j"][:2] = [0, 728], [728, 0]
+    marks = np.zeros(n, np.uint8)
+    fp, st = ts.train_fern(64, cand, 1, 0, 1, True, 0.5)
+    wfp, wst = oracle.train_fern(t, marks, 64, cand, 1, 0, 1, True, 0.5)
+    assert np.array_equal(fp, wfp) and np.array_equal(ts.marks(), marks)
+    stats_equal(st[63], wst[63])
+    s1 = ts.eval_split(wfp, 63, 0.5)
+    stats_equal(s1, oracle.eval_split(t, marks, wfp, 63, 0.5))
+    with pytest.raises(g.GpcError):
+        ts.train_fern(65, np.concatenate([cand, cand[:1]]), 1, 0, 1, False, 0.5)
+    # 64 intercepts straddling the whole difference range
+    for taulo in (-300, -32, 200):
+        marks2 = np.random.default_rng(taulo & 0xFF).integers(0, 4, n).astype(np.uint8)
+        ts.marks(marks2)
+        c2 = make_cands(3 * 2, 43)
+        fp, st = ts.train_fern(3, c2, 2, taulo, taulo + 64, False, 0.3)
+        want = marks2.copy()
+        wfp, wst = oracle.train_fern(t, want, 3, c2, 2, taulo, taulo + 64, False, 0.3)
+        assert np.array_equal(fp, wfp)
+        for level in range(3):
+            stats_equal(st[level], wst[level])
+    ts.close()
