@@ -69,3 +69,12 @@ def test_supports(case, oracle, forest_paths, forest, mode):
         assert np.all(supp["d"] == want["all_d"])
     # rows H-15, H-14 carry code 0 (never computed): last support row is H-16
     assert supp["y"].max() == c["H"] - 16
+
+
+def test_fixture_matches_the_survey_table():
+    """The JSON fixture is a transcription of SURVEY.md Appendix C (vectors of the compiled reference)."""
+    import subprocess
+    import sys
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call([sys.executable, os.path.join(here, "golden", "check_against_survey.py")])
