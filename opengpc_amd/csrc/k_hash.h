@@ -303,11 +303,14 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
 #pragma unroll
         for (int t = 17; t < 25; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
       }
-      if (T > 25) {
+      if (T > 25) {  // the last plane holds tests 25 .. min(T, 32) - 1: no padded tests here (T = 30: 5, not 7)
 #pragma unroll
-        for (int t = 25; t < 32; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+        for (int t = 25; t < 32; ++t)
+          if (t < T) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);  // wave-uniform
       }
     }
+    const int n3 = max(1, min(T, 32) - 25);                     // tests that went into the last plane (T <= 25: plane empty, ~p3 = 0)
+    const uint32_t m3 = 0x01010101u * ((1u << n3) - 1u);       // n3 = 7: 0x7F7F7F7F
     // test 8 is OR-ed into bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask)
     const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
 #pragma unroll
@@ -316,7 +319,8 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
       const uint32_t q0 = NAIVE ? ~p0[r] : (~p0[r] | ((~p8[r] >> 7) & m8));
       const uint32_t q1 = ~p1[r];
       const uint32_t q2 = ~p2[r];
-      const uint32_t q3 = NAIVE ? ~p3[r] : ((~p3[r] >> 1) & SW_M);
+      // P3 saw n3 tests (first one now n3 - 1 places below bit 7): bring the first down to bit 0
+      const uint32_t q3 = NAIVE ? ~p3[r] : ((~p3[r] >> (8 - n3)) & m3);
       // transpose 4 planes x 4 pixels -> 4 codes (byte k of code j = plane k, byte j)
       const uint32_t lo01 = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
       const uint32_t hi01 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
