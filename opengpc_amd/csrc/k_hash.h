@@ -12,10 +12,12 @@
 //     bytes, so a tap for 4 pixels is ONE ALIGNED ds_read_b32 from copy (dx & 3) at
 //     `lane base + SGPR offset + row immediate` (unaligned LDS dwords work on gfx950 but
 //     measured ~20x slower).  64 lanes read 256 contiguous bytes: conflict-free, and 4x fewer
-//     LDS instructions than a byte gather -- LDS issue rate, not HBM, bounds this kernel;
-//   * the four unsigned byte compares of a test are done SWAR in 5 VALU ops and shifted into
-//     byte planes exactly like the reference's out[0..3] registers (7 ops per test and 4
-//     pixels); the planes are transposed into 4 codes with v_perm_b32 at the end;
+//     LDS instructions than a byte gather.  VALU issue bounds this kernel: its instruction count
+//     x 4 cycles per wave64 instruction is its run time;
+//   * the four unsigned byte compares of a test are done SWAR in 4 VALU ops (and, or, sub,
+//     v_bitop3) and shifted into byte planes exactly like the reference's out[0..3] registers
+//     (2 more: 6 ops per test and 4 pixels, + 2 address adds per test); the planes are
+//     transposed into 4 codes with v_perm_b32 at the end;
 //   * the tests (packed LDS offsets, tau) arrive as a by-value kernel argument and live in
 //     SGPRs; the test loop is fully unrolled in branch-free groups so reads are batched.
 // No MFMA: this is gather/compare.
