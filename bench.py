@@ -31,7 +31,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256,
                     help="pairs per GPU per step: BASELINE configs[3]'s batch of 256 pairs, one such batch per GPU "
-                         "(measured: 32 -> 119, 64 -> 120, 128 -> 126, 256 -> 132, 512 -> 136, 1024 -> 133 Gpix/s)")
+                         "(measured: 32 -> 125, 256 -> 150, 384 -> 152, 512 -> 155 Gpix/s; larger batches only amortise "
+                         "the four launch gaps further)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=436)
     ap.add_argument("--forest", default=os.path.join(ROOT, "forests", "defaultZeroForest.txt"))
