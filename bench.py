@@ -21,7 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-DOMINANT_KERNEL = "k_row_match"
+DOMINANT_KERNEL = "k_row_join"
 
 
 def parse_args():
@@ -244,7 +244,7 @@ def main():
         alg = {
             "k_preprocess": 6.0 * W * H * B,               # raw read + smooth/grad write, both images
             "k_hash": 4.0 * W * H * B + 12.0 * N_step,      # smooth+grad read, key+index write
-            "k_row_match": 36.0 * N_step,                   # sort read+write once, match read
+            "k_row_join": 36.0 * N_step,                   # sort read+write once, match read
             "k_gather_rows": 12.0 * M_step,                 # supports out
         }
         kinfo = {}

@@ -11,7 +11,9 @@
  * Conventions
  *   - plain pointers and sizes only; every function returns a gpc_status (0 = ok);
  *   - images are 8-bit, row-major, `width` a multiple of 16 (reference asserts this,
- *     filter.hpp:294,405,549), tightly packed (stride == width);
+ *     filter.hpp:294,405,549), tightly packed (stride == width); width <= 16384 and
+ *     width * height <= 2^30, larger images are refused with GPC_E_UNSUPPORTED (the reference
+ *     has no such limit);
  *   - outputs are caller-allocated with an explicit capacity; the true count is
  *     always returned, GPC_E_CAPACITY if it did not fit (the first `cap` entries are
  *     valid);
@@ -41,7 +43,7 @@ typedef enum {
   GPC_E_NO_FOREST = 5,    /* match/hash called before gpc_hip_set_forest                 */
   GPC_E_FOREST_RANGE = 6, /* a test offset leaves the 27x27 patch                        */
   GPC_E_IO = 7,           /* forest file could not be opened / parsed                    */
-  GPC_E_UNSUPPORTED = 8   /* reserved: a setting this build cannot honour                */
+  GPC_E_UNSUPPORTED = 8   /* a size / setting this build cannot honour (width > 16384, ...) */
 } gpc_status;
 
 /* == ndb::Support, lib/gpc/buffer.hpp:91-97 (12 bytes) */
@@ -222,6 +224,9 @@ int gpc_hip_set_kernel_timing_mask(gpc_hip_ctx* ctx, unsigned mask);
 int gpc_hip_reset_kernel_timing(gpc_hip_ctx* ctx);
 int gpc_hip_kernel_count(void);
 const char* gpc_hip_kernel_name(int index);
+/* The profiler's (rocprofv3) name of the template instantiation this context last launched under timing slot
+ * `index`, e.g. "gpc::k_row_join<4, 256, false>"; "" before the first launch. */
+const char* gpc_hip_kernel_launch_name(const gpc_hip_ctx* ctx, int index);
 int gpc_hip_kernel_time(gpc_hip_ctx* ctx, int index, float* total_ms, int* launches);
 
 #ifdef __cplusplus

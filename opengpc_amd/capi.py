@@ -74,7 +74,7 @@ SYMBOLS = [
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
-    "gpc_hip_kernel_name", "gpc_hip_kernel_time",
+    "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
     "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
     "gpc_hip_train_eval_split", "gpc_hip_train_mark_split_samples", "gpc_hip_train_fern",
     "gpc_hip_train_begin_fern", "gpc_hip_train_eval_level", "gpc_hip_train_commit_level",
@@ -95,6 +95,8 @@ def load():
     L.gpc_hip_last_error.restype = C.c_char_p
     L.gpc_hip_last_error.argtypes = [C.c_void_p]
     L.gpc_hip_kernel_name.restype = C.c_char_p
+    L.gpc_hip_kernel_launch_name.restype = C.c_char_p
+    L.gpc_hip_kernel_launch_name.argtypes = [C.c_void_p, C.c_int]
     L.gpc_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.gpc_hip_destroy.argtypes = [C.c_void_p]
     L.gpc_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -349,6 +351,11 @@ class Context:
 
     def reset_kernel_timing(self):
         self._ck(self.L.gpc_hip_reset_kernel_timing(self.h))
+
+    def kernel_launch_names(self):
+        """{timing slot name: rocprofv3 name of the instantiation last launched there}"""
+        return {self.L.gpc_hip_kernel_name(i).decode(): self.L.gpc_hip_kernel_launch_name(self.h, i).decode()
+                for i in range(self.L.gpc_hip_kernel_count())}
 
     def kernel_times(self):
         """{kernel name: (total ms, launches)} since the last reset."""

@@ -17,9 +17,8 @@
 #include "k_hash.h"
 #include "k_hashtable.h"
 #include "k_preprocess.h"
-#include "k_rowbucket.h"
 #include "k_rowjoin.h"
-#include "k_rowmatch.h"
+#include "k_rows.h"
 #include "k_train.h"
 
 namespace {
@@ -27,7 +26,7 @@ namespace {
 enum KernelId {
   KID_PREPROCESS = 0,
   KID_HASH,
-  KID_ROW_MATCH,
+  KID_ROW_JOIN,
   KID_GATHER_ROWS,
   KID_MASK,
   KID_GLOBAL_KEYS,
@@ -37,7 +36,7 @@ enum KernelId {
   KID_COUNT
 };
 const char* const kKernelNames[KID_COUNT] = {
-    "k_preprocess", "k_hash", "k_row_match", "k_gather_rows",
+    "k_preprocess", "k_hash", "k_row_join", "k_gather_rows",
     "k_mask", "k_global_keys", "k_global_sort", "k_global_match", "k_train_eval"};
 
 struct DevBuf {
@@ -74,7 +73,9 @@ struct gpc_hip_ctx {
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
   int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
-  int row_kernel = 0;  // GPC_HIP_ROWMATCH = join (0, default) | bucket (1) | lds (2): row kernel variants (A/B checks)
+
+  // rocprof name of the instantiation last launched under each timing slot (bench.py reports it)
+  char launch_name[KID_COUNT][96] = {{0}};
 
   // timing
   bool timing = false;
@@ -163,7 +164,9 @@ struct Timed {
 int check_dims(int W, int H) {
   if (W <= 0 || H <= 0 || (W % 16) != 0) return GPC_E_INVALID;
   if (W < 2 * GPC_R + 16 || H < 2 * GPC_R + 4) return GPC_E_INVALID;
-  if (W > 16384 || (long)W * H > (1l << 30)) return GPC_E_INVALID;
+  // the reference takes any multiple of 16; here a row must fit one workgroup's join table (k_rowjoin.h) and a
+  // pixel index 30 bits
+  if (W > 16384 || (long)W * H > (1l << 30)) return GPC_E_UNSUPPORTED;
   return GPC_OK;
 }
 
@@ -196,9 +199,9 @@ bool next_int(const char*& p, int& v) {
 
 // ---------------------------------------------------------------- pipeline stages
 
-int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                      void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
-int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                         void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
 
 // raw0/raw1 device pointers; fills smooth, grad for npairs*sides images
@@ -218,6 +221,7 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   const int rows = small ? PP_ROWS_SMALL : PP_ROWS;
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
+  snprintf(c->launch_name[KID_PREPROCESS], sizeof c->launch_name[0], "gpc::k_preprocess<%s, %d>", c->naive ? "true" : "false", rows);
 #define LAUNCH_PRE(NAIVE, ROWS)                                                                              \
   hipLaunchKernelGGL((gpc::k_preprocess<NAIVE, ROWS>), grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1, \
                      (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p)
@@ -255,6 +259,8 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
+  snprintf(c->launch_name[KID_HASH], sizeof c->launch_name[0], "gpc::k_hash<%s, %s, %s>", tau ? "true" : "false",
+           dense ? "true" : "false", c->naive ? "true" : "false");
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
                      d_cand, d_codes, W, H, NAIVE ? c->forest_naive : c->forest, st, tpw)
@@ -274,76 +280,100 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   return GPC_OK;
 }
 
-// code images of npairs pairs -> supports / correspondences in d_out
-int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+// Significant bits of the codes the current forest can produce: the join buckets its matches on the
+// TOP ones of these (k_rowjoin.h, step 4).  SSE placement (filter.hpp:574-595): test t -> bit t for
+// t <= 7, test 8 is OR-ed into bit 0, test t -> bit t-1 for t >= 9; Naive (filter.hpp:245-249): T bits.
+int code_bits(const gpc_hip_ctx* c) {
+  const int T = c->forest.num_tests;
+  if (c->naive) return T;
+  return T <= 8 ? T : T - 1;
+}
+
+// SSE=OFF arithmetic with 32 tests: codes use bit 31 and 0xFFFFFFFF is a code (k_rowjoin.h, WIDE)
+bool wide_codes(const gpc_hip_ctx* c) { return c->naive && c->forest.num_tests == 32; }
+
+// How the join kernel covers a row of W pixels: NT threads x SPT pixel slots, table of 1 << log2s slots.
+struct JoinPlan {
+  int nt, spt, log2s, rshift;
+  size_t lds;
+};
+
+JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
+  JoinPlan p;
+  p.spt = 1;
+  p.nt = 256;
+  while (p.spt * p.nt < W && p.spt < 4) p.spt <<= 1;    // <= 1024 px: 256 threads, 8 workgroups per CU
+  while (p.spt * p.nt < W && p.nt < 1024) p.nt <<= 1;   // <= 4096 px: more threads per row
+  if (c->join_nt && 4 * c->join_nt >= W) {  // tuning override (GPC_HIP_JOIN_NT): threads per row, slots per thread follow
+    p.nt = c->join_nt;
+    p.spt = 1;
+    while (p.spt * p.nt < W) p.spt <<= 1;
+  }
+  while (p.spt * p.nt < W && p.spt < 16) p.spt <<= 1;   // <= 16384 px: 1024 threads with 8 / 16 slots each
+  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5 (up to the 16384 slots = 128 KiB
+  // one workgroup can have: beyond 8218 px the table fills further, W-26 < 16384 keys always fit);
+  // S >= NT*SPT because the rank phase reuses the key table as bucket counters
+  p.log2s = 1;
+  while ((1 << p.log2s) < p.nt * p.spt || ((1 << p.log2s) < 2 * (W - 2 * GPC_R) && p.log2s < 14)) ++p.log2s;
+  p.lds = ((size_t)8 * ((1u << p.log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
+  int log2nb = 0;
+  while ((1 << log2nb) < p.nt * p.spt) ++log2nb;
+  const int bits = wide_codes(c) ? 32 : code_bits(c);
+  p.rshift = bits > log2nb ? bits - log2nb : 0;
+  return p;
+}
+
+// code images of npairs pairs -> supports / correspondences in d_out.
+// d_cand: the candidate bytes the hash kernel used ([2*npairs][H][W]: grad, or the scattered mask list)
+int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
               void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
   const int apply_filter = (mode == 0);
-  if (s->use_hashtable) return run_hashtable_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
+  if (s->use_hashtable) return run_hashtable_match(c, W, H, npairs, s, mode, d_cand, d_out, cap, d_counts, d_ncand);
   if (s->epipolar_mode) {
     CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)W * H * npairs));
     CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * npairs * 2));
     // |dy| is 0 for every epipolar match; a negative tolerance rejects everything
     int disp_high = s->disp_high;
     if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
-    dim3 grid(H - 2 * GPC_R, npairs);
-    // join kernel (k_rowjoin.h): NT threads x SPT pixel slots per thread cover a row; wide rows
-    // get more threads (their table leaves room for only 1-3 workgroups per CU).  The counting-join
-    // (k_rowbucket.h) and LDS-sort (k_rowmatch.h) kernels remain for A/B checks / very wide images.
-    int spt = 1;
-    while (spt * RB_THREADS < W) spt <<= 1;   // bucket variant: 256 threads
-    int jspt = 1, jnt = 256;
-    while (jspt * jnt < W && jspt < 4) jspt <<= 1;
-    while (jspt * jnt < W && jnt < 1024) jnt <<= 1;
-    if (c->join_nt) {  // tuning override (GPC_HIP_JOIN_NT): threads per row, slots per thread follow
-      jnt = c->join_nt;
-      jspt = 1;
-      while (jspt * jnt < W && jspt < 4) jspt <<= 1;
-    }
-    int log2s = 1;  // only left codes are inserted: S >= 2*(W-26) keeps the load factor <= 0.5;
-                    // S >= NT*SPT because the rank phase reuses the accumulators as bucket counters
-    while ((1 << log2s) < 2 * (W - 2 * GPC_R) || (1 << log2s) < jnt * jspt) ++log2s;
-    const size_t join_lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
-    const bool use_join = c->row_kernel == 0 && jspt * jnt >= W && join_lds <= 150 * 1024;
-    const size_t bucket_lds = (size_t)20 * RB_THREADS * spt + 16;
-    const bool use_bucket = c->row_kernel == 1 && spt <= 16;
+    const JoinPlan jp = plan_join(c, W);
+    if (jp.nt * jp.spt < W) return GPC_E_UNSUPPORTED;  // unreachable below check_dims' 16384 px
     {
-      Timed t(c, KID_ROW_MATCH);
-      if (use_bucket) {
-        // counting (radix-bucket) join, k_rowbucket.h
-#define LAUNCH_BUCKET(SPT)                                                                         \
-  hipLaunchKernelGGL(gpc::k_row_bucket<SPT>, grid, dim3(RB_THREADS), bucket_lds, c->stream,        \
-                     (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                   \
-                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p)
-        switch (spt) {
-          case 1: LAUNCH_BUCKET(1); break;
-          case 2: LAUNCH_BUCKET(2); break;
-          case 4: LAUNCH_BUCKET(4); break;
-          case 8: LAUNCH_BUCKET(8); break;
-          default: LAUNCH_BUCKET(16); break;
-        }
-#undef LAUNCH_BUCKET
-      } else if (use_join) {
-        int rpw = c->join_rpw > 0 ? c->join_rpw : 1;
-        const dim3 jgrid((H - 2 * GPC_R + rpw - 1) / rpw, npairs);
-#define LAUNCH_JOIN(SPT, NT)                                                                      \
-  hipLaunchKernelGGL((gpc::k_row_join<SPT, NT>), jgrid, dim3(NT), join_lds, c->stream,            \
-                     (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,                  \
-                     (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, log2s, rpw)
-        if (jnt == 1024) { if (jspt == 4) LAUNCH_JOIN(4, 1024); else if (jspt == 2) LAUNCH_JOIN(2, 1024); else LAUNCH_JOIN(1, 1024); }
-        else if (jnt == 512) { if (jspt == 4) LAUNCH_JOIN(4, 512); else if (jspt == 2) LAUNCH_JOIN(2, 512); else LAUNCH_JOIN(1, 512); }
-        else { if (jspt == 4) LAUNCH_JOIN(4, 256); else if (jspt == 2) LAUNCH_JOIN(2, 256); else LAUNCH_JOIN(1, 256); }
+      Timed t(c, KID_ROW_JOIN);
+      const int rpw = c->join_rpw > 0 ? c->join_rpw : 1;
+      const dim3 jgrid((H - 2 * GPC_R + rpw - 1) / rpw, npairs);
+      const bool wide = wide_codes(c);
+      snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join<%d, %d, %s>", jp.spt, jp.nt,
+               wide ? "true" : "false");
+#define LAUNCH_JOIN(SPT, NT, WIDE)                                                                            \
+  do {                                                                                                        \
+    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, NT, WIDE>);                          \
+    if (jp.lds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jp.lds)); \
+    hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
+                       (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
+                       (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
+                       jp.rshift, rpw);                                                                       \
+  } while (0)
+#define LAUNCH_JOIN_W(SPT, NT) do { if (wide) LAUNCH_JOIN(SPT, NT, true); else LAUNCH_JOIN(SPT, NT, false); } while (0)
+#define LAUNCH_JOIN_S(NT)                      \
+  switch (jp.spt) {                            \
+    case 1: LAUNCH_JOIN_W(1, NT); break;       \
+    case 2: LAUNCH_JOIN_W(2, NT); break;       \
+    default: LAUNCH_JOIN_W(4, NT); break;      \
+  }
+      if (jp.nt == 1024) {
+        if (jp.spt == 16) LAUNCH_JOIN_W(16, 1024);
+        else if (jp.spt == 8) LAUNCH_JOIN_W(8, 1024);
+        else LAUNCH_JOIN_S(1024)
+      } else if (jp.nt == 512) { LAUNCH_JOIN_S(512) }
+      else { LAUNCH_JOIN_S(256) }
+#undef LAUNCH_JOIN_S
+#undef LAUNCH_JOIN_W
 #undef LAUNCH_JOIN
-      } else {
-        const int nmax = pow2_at_least(2 * (W - 2 * GPC_R));
-        const size_t lds = sizeof(unsigned long long) * (size_t)nmax;
-        hipLaunchKernelGGL(gpc::k_row_match, grid, dim3(RM_THREADS), lds, c->stream,
-                           (const uint32_t*)c->codes.p, W, H, disp_high, apply_filter,
-                           (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p);
-      }
       HIPCHK(c, hipGetLastError());
     }
     {
       Timed t(c, KID_GATHER_ROWS);
+      snprintf(c->launch_name[KID_GATHER_ROWS], sizeof c->launch_name[0], "gpc::k_gather_rows");
       const int gr = ((long)((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS) * npairs >= 2048) ? GR_ROWS : 1;
       hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + gr - 1) / gr, npairs), dim3(RM_THREADS), 0, c->stream,
                          (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
@@ -352,7 +382,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     }
     return GPC_OK;
   }
-  return run_global_match(c, W, H, npairs, s, mode, d_out, cap, d_counts, d_ncand);
+  return run_global_match(c, W, H, npairs, s, mode, d_cand, d_out, cap, d_counts, d_ncand);
 }
 
 // Shared set-up of the two device-wide-sort matchers (k_global.h, k_hashtable.h); every launch
@@ -412,27 +442,28 @@ int radix_passes(gpc_hip_ctx* c, const GlobalPlan& g, int npairs, uint32_t* keys
 }
 
 // Non-epipolar mode: one device-wide stable radix sort per pair (k_global.h).
-int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                      void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
   GlobalPlan g;
   CHK(plan_global(c, W, H, npairs, mode, cap, false, g));
   const int apply_filter = (mode == 0);
   const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;  // 32-bit codes: 0xFFFFFFFF is told from the sentinel by the candidate byte
   const int32_t* stats = (const int32_t*)c->stats.p;
   uint32_t* keys[2] = {(uint32_t*)c->gkeys[0].p, (uint32_t*)c->gkeys[1].p};
   uint32_t* vals[2] = {(uint32_t*)c->gvals[0].p, (uint32_t*)c->gvals[1].p};
   dim3 rgrid(H - 2 * GPC_R, 2, npairs);
   {
     Timed t(c, KID_GLOBAL_KEYS);
-    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, g.rowcnt, stats,
+    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, wcand, W, H, g.rowcnt, stats,
                        g.gmisc, g.bs);
-    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, wcand, W, H,
                        (const int32_t*)g.rowcnt, stats, keys[0], vals[0], g.gmisc, g.bs);
     HIPCHK(c, hipGetLastError());
   }
   {
     Timed t(c, KID_GLOBAL_SORT);
-    CHK(radix_passes(c, g, npairs, keys, vals, 4));  // 31-bit codes
+    CHK(radix_passes(c, g, npairs, keys, vals, 4));  // all 32 code bits
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
@@ -452,13 +483,14 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
 }
 
 // useHashtable mode (hashmatch.hpp): stable radix sort by bucket id + one thread per bucket (k_hashtable.h)
-int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode,
+int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                         void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
   GlobalPlan g;
   CHK(plan_global(c, W, H, npairs, mode, cap, true, g));
   const int apply_filter = (mode == 0);
   const int epi = s->epipolar_mode ? 1 : 0;
   const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;
   const int32_t* stats = (const int32_t*)c->stats.p;
   uint32_t* codes0 = (uint32_t*)c->gkeys[0].p;
   uint32_t* kv0 = (uint32_t*)c->gvals[0].p;
@@ -467,9 +499,9 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
   dim3 rgrid(H - 2 * GPC_R, 2, npairs);
   {
     Timed t(c, KID_GLOBAL_KEYS);
-    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H, g.rowcnt, stats,
+    hipLaunchKernelGGL(gpc::k_g_rowcount, rgrid, dim3(RM_THREADS), 0, c->stream, codes, wcand, W, H, g.rowcnt, stats,
                        g.gmisc, g.bs);
-    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, W, H,
+    hipLaunchKernelGGL(gpc::k_g_build, rgrid, dim3(RM_THREADS), 0, c->stream, codes, wcand, W, H,
                        (const int32_t*)g.rowcnt, stats, codes0, kv0, g.gmisc, g.bs);
     hipLaunchKernelGGL(gpc::k_ht_bucket_ids, dim3(g.nmblk, npairs), dim3(256), 0, c->stream,
                        (const uint32_t*)codes0, (const uint32_t*)kv0, (const int32_t*)g.gmisc, make_divw(W), epi, keys[0],
@@ -561,22 +593,12 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
     return GPC_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  // the row-match kernel may need more than 64 KiB of dynamic LDS for very wide images
-  const int max_dyn = 160 * 1024 - 2048;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_match),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_join<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_row_bucket<16>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
   const char* ht = getenv("GPC_HIP_HASH_TPW");
   if (ht && atoi(ht) > 0 && atoi(ht) <= 64) c->hash_tpw = atoi(ht);
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   const char* jn = getenv("GPC_HIP_JOIN_NT");
   if (jn && (atoi(jn) == 256 || atoi(jn) == 512 || atoi(jn) == 1024)) c->join_nt = atoi(jn);
-  const char* rm = getenv("GPC_HIP_ROWMATCH");
-  c->row_kernel = (rm && !strcmp(rm, "lds")) ? 2 : (rm && !strcmp(rm, "bucket")) ? 1 : 0;
   *out = c;
   return GPC_OK;
 }
@@ -855,7 +877,7 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   CHK(run_hash(c, d_sm, d_gr, d_cm, W, H, 2, false, (uint32_t*)c->codes.p));
-  CHK(run_match(c, W, H, 1, s, mode, c->out.p, cap, (int32_t*)c->counts.p, nullptr));
+  CHK(run_match(c, W, H, 1, s, mode, d_cm, c->out.p, cap, (int32_t*)c->counts.p, nullptr));
   int32_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(&cnt, c->counts.p, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -894,7 +916,7 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
                (uint32_t*)c->codes.p));
-  CHK(run_match(c, W, H, npairs, s, 0, d_out, cap_per_pair, d_counts, d_ncand));
+  CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out, cap_per_pair, d_counts, d_ncand));
   return GPC_OK;
 }
 
@@ -1260,6 +1282,10 @@ int gpc_hip_kernel_count(void) { return KID_COUNT; }
 
 const char* gpc_hip_kernel_name(int index) {
   return (index >= 0 && index < KID_COUNT) ? kKernelNames[index] : "";
+}
+
+const char* gpc_hip_kernel_launch_name(const gpc_hip_ctx* c, int index) {
+  return (c && index >= 0 && index < KID_COUNT) ? c->launch_name[index] : "";
 }
 
 int gpc_hip_kernel_time(gpc_hip_ctx* c, int index, float* total_ms, int* launches) {

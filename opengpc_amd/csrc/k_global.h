@@ -7,7 +7,7 @@
 // Without the row in the state, a code must be unique over the whole left image and over
 // the whole right image.  Both descriptor sets go into ONE array of (code, side<<31 | k)
 // records -- left records first, each side in mask (row-major) order -- which a stable LSD
-// radix sort (4 passes x 8 bits over the 31-bit codes) orders by (code, side, k).  Matches
+// radix sort (4 passes x 8 bits: all 32 code bits) orders by (code, side, k).  Matches
 // are then read off neighbouring records exactly as in the per-row kernel, including the
 // tail quirks of the reference's merge scan for the group of the largest right-image code.
 //
@@ -15,7 +15,7 @@
 // the worst case N = 2*(W-26)*(H-26) and surplus workgroups exit.
 #pragma once
 #include "gpc_device.h"
-#include "k_rowmatch.h"
+#include "k_rows.h"
 
 namespace gpc {
 
@@ -29,7 +29,8 @@ namespace gpc {
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_CHUNK (GS_TILE / GS_WAVES)    // records per wave
 
-// gmisc layout (int32, GM_STRIDE per pair): [0] number of records N, [1] largest right-image code, [2] N_L
+// gmisc layout (int32, GM_STRIDE per pair): [0] number of records N, [1] largest right-image code (unsigned;
+// meaningful when N > N_L), [2] N_L
 #define GM_N 0
 #define GM_MAXR 1
 #define GM_NL 2
@@ -48,7 +49,14 @@ struct GpcBatchStrides {
 
 // ---- build the record array from the two code images of one pair --------------------
 // grid: (H - 26, 2, npairs)
-__global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __restrict__ codes, int W, int H,
+// A pixel of the code image is a record: its code is not the sentinel, or -- 32-bit codes only (cand != nullptr,
+// see k_rowjoin.h WIDE) -- it is the code 0xFFFFFFFF of a candidate (the hash kernel's rule: byte set, inside the margin).
+__device__ __forceinline__ bool g_is_record(uint32_t c, const uint8_t* __restrict__ cand_row, int x, int W) {
+  return c != GPC_NOCAND || (cand_row != nullptr && x >= GPC_R && x < W - GPC_R && cand_row[x] != 0);
+}
+
+__global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __restrict__ codes,
+                                                           const uint8_t* __restrict__ cand, int W, int H,
                                                            int32_t* __restrict__ rowcnt,
                                                            const int32_t* __restrict__ stats,
                                                            int32_t* __restrict__ gmisc, GpcBatchStrides bs) {
@@ -58,8 +66,9 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __res
   stats += pair * 2 * GPC_STAT_STRIDE;
   gmisc += pair * GM_STRIDE;
   const uint32_t* row = codes + ((long)side * H + y) * W;
+  const uint8_t* crow = cand ? cand + pair * bs.codes + ((long)side * H + y) * W : nullptr;
   int v = 0;
-  for (int x = threadIdx.x; x < W; x += RM_THREADS) v += row[x] != GPC_NOCAND;
+  for (int x = threadIdx.x; x < W; x += RM_THREADS) v += g_is_record(row[x], crow, x, W);
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __shared__ int s_part[RM_THREADS / 64];
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
@@ -72,13 +81,14 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_rowcount(const uint32_t* __res
       const int nl = stats[GPC_STAT_NCAND], nr = stats[GPC_STAT_STRIDE + GPC_STAT_NCAND];
       gmisc[GM_N] = nl + nr;
       gmisc[GM_NL] = nl;
-      gmisc[GM_MAXR] = -1;
+      gmisc[GM_MAXR] = 0;
     }
   }
 }
 
 // grid: (H - 26, 2, npairs); runs after k_g_rowcount
-__global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restrict__ codes, int W, int H,
+__global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restrict__ codes,
+                                                        const uint8_t* __restrict__ cand, int W, int H,
                                                         const int32_t* __restrict__ rowcnt,
                                                         const int32_t* __restrict__ stats,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -95,11 +105,12 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restri
   int total = block_prefix_rows(rowcnt + side * H, GPC_R, y);
   if (side) total += stats[GPC_STAT_NCAND];  // right records follow all left records
   const uint32_t* row = codes + ((long)side * H + y) * W;
-  int max_r = -1;
+  const uint8_t* crow = cand ? cand + pair * bs.codes + ((long)side * H + y) * W : nullptr;
+  uint32_t max_r = 0u;
   for (int x0 = 0; x0 < W; x0 += RM_THREADS) {
     const int x = x0 + threadIdx.x;
     const uint32_t c = (x < W) ? row[x] : GPC_NOCAND;
-    const bool valid = c != GPC_NOCAND;
+    const bool valid = x < W && g_is_record(c, crow, x, W);
     const unsigned long long m = __ballot(valid);
     if (lane == 0) s_wcnt[wave] = __popcll(m);
     __syncthreads();
@@ -109,14 +120,14 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_build(const uint32_t* __restri
       const int pos = off + __popcll(m & lanemask_lt());
       keys[pos] = c;
       vals[pos] = ((uint32_t)side << 31) | (uint32_t)(y * W + x);
-      if (side) max_r = max(max_r, (int)c);
+      if (side) max_r = max(max_r, c);
     }
     for (int w = 0; w < RM_THREADS / 64; ++w) total += s_wcnt[w];
     __syncthreads();
   }
-  if (side) {
-    for (int o = 32; o > 0; o >>= 1) max_r = max(max_r, __shfl_xor(max_r, o));
-    if (lane == 0 && max_r >= 0) atomicMax(&gmisc[GM_MAXR], max_r);
+  if (side) {  // unsigned: 32-bit codes use bit 31
+    for (int o = 32; o > 0; o >>= 1) max_r = max(max_r, (uint32_t)__shfl_xor((int)max_r, o));
+    if (lane == 0 && max_r) atomicMax(reinterpret_cast<uint32_t*>(&gmisc[GM_MAXR]), max_r);
   }
 }
 
@@ -297,19 +308,24 @@ __global__ __launch_bounds__(GS_THREADS) void k_g_scatter(const uint32_t* __rest
 #define GMT_RPT 4                          // sorted records per thread
 #define GMT_TILE (RM_THREADS * GMT_RPT)    // sorted records per workgroup
 
-// Record i (staged in LDS: s_k[q] / s_v[q] hold record j0 - 1 + q) is a left record whose code
-// occurs once on the left and once on the right (tail quirk: once + twice for the largest right code).
-__device__ __forceinline__ bool g_match_at(const uint32_t* s_k, const uint32_t* s_v, int q, const GpcDivW& wd,
-                                           uint32_t tail_code, int disp_high, int vtol, int apply_filter, int4& m) {
+// Record j = jm1 + q (staged in LDS: s_k[q] / s_v[q] hold record jm1 + q, jm1 = j0 - 1) is a left record whose
+// code occurs once on the left and once on the right (tail quirk: once + twice for the largest right code).
+// Neighbours are told apart from "beyond the last record" by their index, not by a sentinel: every 32-bit
+// value can be a code (k_rowjoin.h, WIDE).
+__device__ __forceinline__ bool g_match_at(const uint32_t* s_k, const uint32_t* s_v, int q, int jm1, int N,
+                                           const GpcDivW& wd, bool have_tail, uint32_t tail_code, int disp_high,
+                                           int vtol, int apply_filter, int4& m) {
+  const int j = jm1 + q;
+  if (j >= N) return false;
   const uint32_t code = s_k[q];
   const uint32_t v0 = s_v[q];
-  if (code == 0xFFFFFFFFu || (v0 >> 31)) return false;  // beyond the last record / right record
-  const bool prev_same = s_k[q - 1] == code;
-  const bool n1r = s_k[q + 1] == code && (s_v[q + 1] >> 31);
+  if (v0 >> 31) return false;  // right record
+  const bool prev_same = j > 0 && s_k[q - 1] == code;
+  const bool n1r = j + 1 < N && s_k[q + 1] == code && (s_v[q + 1] >> 31);
   if (prev_same || !n1r) return false;
-  const bool n2 = s_k[q + 2] == code;
-  const bool n3 = s_k[q + 3] == code;
-  const bool ok = (code == tail_code) ? (n2 && !n3) : !n2;
+  const bool n2 = j + 2 < N && s_k[q + 2] == code;
+  const bool n3 = j + 3 < N && s_k[q + 3] == code;
+  const bool ok = (have_tail && code == tail_code) ? (n2 && !n3) : !n2;
   if (!ok) return false;
   const int kl = (int)(v0 & 0x7FFFFFFFu), kr = (int)(s_v[q + 1] & 0x7FFFFFFFu);
   const int yl = divw((uint32_t)kl, wd), yr = divw((uint32_t)kr, wd);
@@ -339,12 +355,13 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match(const uint32_t* __restri
   gmisc += blockIdx.y * GM_STRIDE;
   const int N = gmisc[GM_N];
   const uint32_t tail_code = (uint32_t)gmisc[GM_MAXR];
+  const bool have_tail = N > gmisc[GM_NL];  // there are right records
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j0 = blockIdx.x * GMT_TILE;
   for (int q = tid; q < GMT_TILE + 4; q += RM_THREADS) {
     const int j = j0 - 1 + q;
     const bool in = j >= 0 && j < N;
-    s_k[q] = in ? keys[j] : 0xFFFFFFFFu;  // never a code (codes have 31 bits)
+    s_k[q] = in ? keys[j] : 0u;
     s_v[q] = in ? vals[j] : 0u;
   }
   __syncthreads();
@@ -352,7 +369,8 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match(const uint32_t* __restri
 #pragma unroll
   for (int k = 0; k < GMT_RPT; ++k) {
     int4 m;
-    if (g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, wd, tail_code, disp_high, vtol, apply_filter, m)) hits |= 1u << k;
+    if (g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, j0 - 1, N, wd, have_tail, tail_code, disp_high, vtol, apply_filter, m))
+      hits |= 1u << k;
   }
   const uint32_t cnt = (uint32_t)__popc(hits);
   const uint32_t incl = wave_incl_scan(cnt);
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(RM_THREADS) void k_g_match(const uint32_t* __restri
     if ((hits >> k) & 1u) {
       if (pos < cap) {
         int4 m;
-        (void)g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, wd, tail_code, disp_high, vtol, apply_filter, m);
+        (void)g_match_at(s_k, s_v, 1 + tid * GMT_RPT + k, j0 - 1, N, wd, have_tail, tail_code, disp_high, vtol, apply_filter, m);
         if (mode == 0) {
           uint32_t* o = reinterpret_cast<uint32_t*>(out) + (long)pos * 3;
           o[0] = m.x;

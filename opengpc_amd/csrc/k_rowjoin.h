@@ -3,7 +3,8 @@
 // Replaces, for settings.epipolarMode_ == true, the descriptor build + `state |= y<<32`
 // (inference.hpp:189-197), Forest::findCorrespondences (std::sort x2 + merge scan,
 // inference.hpp:227-254) and the disparity filter of rectifiedMatch (inference.hpp:384-391).
-// One image row per workgroup (see k_rowmatch.h for why rows are independent).
+// One image row per workgroup: with the row in the upper 32 state bits the reference's global
+// sort is a per-row sort by code, and a source code can only meet target codes of its own row.
 //
 // What the reference's sort+merge decides for a row is, per code c:  cntL(c) == 1 and
 // cntR(c) == 1  (with the tail-quirk variant cntR == 2 for the largest right code of the
@@ -14,20 +15,25 @@
 //      cycles of LDS pipe on MI355X, a returning ds_max ~8);
 //   2. both rows look their code up (plain reads) and mark the slot: a returning ds_or sets the
 //      side's SEEN flag, and a record that finds it already set adds the side's DUP flag; a right
-//      record also leaves its x in the low half of the slot's word (plain 16-bit store: if the
-//      right code is unique there was one writer, otherwise the value is not used);
+//      record ORs its x into the (zeroed) low half of the same word with the same atomic: if the
+//      right code is unique there was one writer, otherwise the value is not used;
 //   3. every left record reads its slot: match iff neither side is DUP and the right side was
 //      SEEN (+ disparity filter);
 //   4. output position = rank of the code among the row's matches, by COUNTING on the top
-//      bits of the code: one returning ds_add per match, an exclusive scan over 256*SPT bucket
-//      counters (DPP wave scan), and a look at the < 1 other matches sharing the bucket.
+//      SIGNIFICANT bits of the code (the host passes the shift: a 30-test forest has 29-bit
+//      codes): one returning ds_add per match, an exclusive scan over the NT*SPT bucket counters
+//      (DPP wave scan), and a look at the < 1 other matches sharing the bucket.
 //      The thread still holds xL and xR, so it writes the packed support straight to its place.
+//
+// 32-bit codes (WIDE): the SSE=OFF arithmetic with a 32-test forest sets bit 31, and the code
+// 0xFFFFFFFF then collides with both sentinels (GPC_NOCAND in the code image, key 0 = code + 1
+// in the table).  The WIDE instantiations read the candidate byte of such pixels to tell them
+// apart and keep the one code that has no table key in three shared counters instead.
 #pragma once
 #include "gpc_device.h"
 
 namespace gpc {
 
-#define RJ_THREADS 256
 #define RJ_EMPTY 0xFFFFFFFFu
 // flags of a table slot (high half of its word; the low half holds a right record's x)
 #define RJ_LSEEN 0x00010000u
@@ -62,7 +68,7 @@ __device__ unsigned long long g_rj_stamps[16];
 #define RJ_STAMP_FLUSH()
 #endif
 
-__device__ __forceinline__ uint32_t rj_hash(uint32_t code, int shift) { return (code * 0x9E3779B1u) >> shift; }
+__device__ __forceinline__ uint32_t rj_hash(uint32_t key, int shift) { return (key * 0x9E3779B1u) >> shift; }
 
 // ---------------------------------------------------------------- the join table
 // Measured on MI355X (profiles/r01_ubench_lds_valu_calibration.txt): a wave-level LDS
@@ -74,87 +80,134 @@ __device__ __forceinline__ uint32_t rj_hash(uint32_t code, int shift) { return (
 // first slot holding a smaller key.  Stored key = code + 1 (0 = empty slot).
 // Only LEFT codes are inserted; right records merely look their code up.  A slot costs 8 bytes
 // (key + one word of flags and x): 16 KiB per 1024-px row and 64 VGPRs, so EIGHT workgroups = 32
-// waves share a CU.  Earlier layouts, per 256 pairs: 12 bytes (count << 16 + x summed into two
-// 32-bit accumulators per slot), six workgroups: 686 us; 10 bytes (two 16-bit counts + 16-bit x),
-// seven: 628 us; this one: 595 us.
+// waves share a CU.
+//
+// The two probe loops are written in gfx950 assembly: the lanes still probing narrow EXEC with
+// v_cmpx and the loop ends on s_cbranch_execnz -- one scalar instruction per round where the
+// compiler's structurised form of the same divergent loop spends five or six on exit masks
+// (the kernel issued 0.72 scalar instructions per vector instruction before; PMC r01_k).
 
-// insert SPT keys per thread (0 = none); the first probes of all slots are issued together
-template <int SPT>
-__device__ __forceinline__ void rj_insert_ordered(uint32_t* __restrict__ t_key, const uint32_t (&k)[SPT],
-                                                  int hshift, uint32_t smask) {
-  uint32_t h[SPT], old[SPT];
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) h[j] = rj_hash(k[j], hshift);
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    old[j] = 0u;
-    if (k[j]) old[j] = atomicMax(&t_key[h[j]], k[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    uint32_t cur = k[j], o = old[j];
-    // o == 0: slot was empty (created) ; o == cur: already present ; o < cur: displaced o ; o > cur: keep cur
-    while (o != 0u && o != cur) {
-      if (o < cur) cur = o;
-      h[j] = (h[j] + 1) & smask;
-      o = atomicMax(&t_key[h[j]], cur);
-    }
-  }
+// continues the ordered insert of key `cur` whose first probe at slot h returned `o`
+// (o == 0: slot was empty -> done; o == cur: already present -> done; o < cur: displaced o, carry
+// it on; o > cur: keep cur and move on).  keys_lds = LDS byte offset of the key table.
+__device__ __forceinline__ void rj_insert_chain(uint32_t keys_lds, uint32_t cur, uint32_t o, uint32_t h, uint32_t smask) {
+  uint32_t addr;
+  unsigned long long sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[cur]\n\t"       // lanes without a record never probe on
+      "v_cmpx_ne_u32_e32 vcc, 0, %[o]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_min_u32_e32 %[cur], %[o], %[cur]\n\t"
+      "v_add_u32_e32 %[h], 1, %[h]\n\t"
+      "v_and_b32_e32 %[h], %[smask], %[h]\n\t"
+      "v_lshl_add_u32 %[addr], %[h], 2, %[base]\n\t"
+      "ds_max_rtn_u32 %[o], %[addr], %[cur]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[o]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
+      "s_cbranch_execnz 1b\n"
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [cur] "+v"(cur), [o] "+v"(o), [h] "+v"(h), [addr] "=&v"(addr), [sv] "=&s"(sv)
+      : [smask] "s"(smask), [base] "s"(keys_lds)
+      : "vcc", "memory");
 }
 
-// slot of key k (k != 0) or ~0u when absent; read-only
-__device__ __forceinline__ uint32_t rj_find(const uint32_t* __restrict__ t_key, uint32_t k, uint32_t first,
-                                            uint32_t h, uint32_t smask) {
-  uint32_t kk = first;
-  while (kk > k) {  // larger keys sit in front of k on its probe path
-    h = (h + 1) & smask;
-    kk = t_key[h];
-  }
-  return kk == k ? h : 0xFFFFFFFFu;
+// slot of key k on its probe path: larger keys sit in front of it.  kk = value of the first probe
+// (pass 0 for a lane without a record).  Returns the slot where the walk stopped and, in kk, what
+// it holds there: kk == k -> found.
+__device__ __forceinline__ uint32_t rj_find_chain(uint32_t keys_lds, uint32_t k, uint32_t& kk, uint32_t h, uint32_t smask) {
+  uint32_t addr;
+  unsigned long long sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_gt_u32_e32 vcc, %[kk], %[k]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_add_u32_e32 %[h], 1, %[h]\n\t"
+      "v_and_b32_e32 %[h], %[smask], %[h]\n\t"
+      "v_lshl_add_u32 %[addr], %[h], 2, %[base]\n\t"
+      "ds_read_b32 %[kk], %[addr]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmpx_gt_u32_e32 vcc, %[kk], %[k]\n\t"
+      "s_cbranch_execnz 1b\n"
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [kk] "+v"(kk), [h] "+v"(h), [addr] "=&v"(addr), [sv] "=&s"(sv)
+      : [k] "v"(k), [smask] "s"(smask), [base] "s"(keys_lds)
+      : "vcc", "memory");
+  return h;
 }
+
+// Occupancy the register allocator aims for: 256- and 512-thread rows keep 8 waves per SIMD (64
+// VGPRs); 1024-thread rows with 8 / 16 pixel slots per thread (W > 4096: one workgroup per CU) get
+// the 128 registers their 16 waves leave them.
+template <int SPT, int NT>
+struct RjOcc {
+  static constexpr int kWaves = (SPT >= 8) ? 4 : 8;
+};
 
 // codes:   [npairs*2][H][W]   (image 2p = left, 2p+1 = right)
+// cand:    [npairs*2][H][W]   candidate bytes (grad, or the caller's scattered mask): WIDE only
 // staged:  [npairs][H][W]     packed (xL | xR<<16), first rowcnt entries of each row valid
 // rowcnt:  [npairs][H]
-// grid: (H - 26, npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
-//       S >= max(2*(W-26), NB)   (only left codes are inserted: load factor <= 0.5)
+// grid: (ceil((H - 26) / rpw), npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
+//       S >= NB, S >= 2*(W-26) where the LDS allows it (only left codes are inserted: load factor
+//       <= 0.5; rows beyond 8218 px fill a 16384-slot table up to W-26 / 16384 < 1)
+// rshift: code >> rshift < NB for every code the forest can produce (host: code bits - log2 NB)
 // dynamic LDS: 8*(S+1) bytes  (16 KiB for W = 1024: 8 workgroups per CU = 32 waves, 64 VGPRs)
-// Wide rows use more threads per row instead of more pixel slots per thread, so that the one
+// Wide rows use more threads per row before more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
-template <int SPT, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_join(
-    const uint32_t* __restrict__ codes, int W, int H, int disp_high, int apply_filter,
+template <int SPT, int NT, bool WIDE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, NT>::kWaves, 8))) void k_row_join(
+    const uint32_t* __restrict__ codes, const uint8_t* __restrict__ cand, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
-    int log2s, int rpw) {
+    int log2s, int rshift, int rpw) {
   constexpr int NB = NT * SPT;
-  constexpr int RSHIFT = 31 - ((NT == 256 ? 8 : NT == 512 ? 9 : 10) + (SPT == 1 ? 0 : SPT == 2 ? 1 : SPT == 4 ? 2 : SPT == 8 ? 3 : 4));
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
-  __shared__ int s_max_r, s_tail_cnt;
+  __shared__ uint32_t s_max_key;
+  __shared__ int s_tail_cnt;
   __shared__ unsigned s_tail_minx;
+  __shared__ int s_sp_l, s_sp_r;   // WIDE: left / right candidates of this row whose code is 0xFFFFFFFF
+  __shared__ unsigned s_sp_minx;   //       smallest x among the right ones
   __shared__ uint32_t s_w[NT / 64];
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
   uint32_t* t_w = rj_lds + (S + 1);       // [S]   per slot: seen / duplicate flags of either side (RJ_*), x of a right record in the low half
   uint32_t* r_cnt = t_key;                // [NB+1] bucket counters -> starts   (reuses t_key, dead after step 2)
   uint32_t* r_key = t_w;                  // [NB]   matched codes, bucket-contiguous (reuses t_w, dead after step 3)
+  const uint32_t keys_lds = (uint32_t)(uintptr_t)t_key;  // low half of the flat address = LDS offset
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int pair = blockIdx.y;
   const int hshift = 32 - log2s;
   const uint32_t smask = (uint32_t)S - 1u;
+  const int last_r = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
 
   // A workgroup handles `rpw` consecutive rows; the NEXT row's codes are fetched into registers
   // while the current row is joined, so only the first row's load latency is exposed.
   const int row0 = GPC_R + blockIdx.x * rpw;
   uint32_t ncl[SPT], ncr[SPT];
+  uint32_t nspl = 0u, nspr = 0u;  // WIDE: bit j = pixel slot j is a candidate whose code is 0xFFFFFFFF
   auto fetch_row = [&](int yy) {
-    const uint32_t* rl = codes + ((long)(pair * 2) * H + yy) * W;
+    const long ro = ((long)(pair * 2) * H + yy) * W;
+    const uint32_t* rl = codes + ro;
     const uint32_t* rr_ = rl + (long)H * W;
+    nspl = nspr = 0u;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const int x = j * NT + tid;
       ncl[j] = (x < W) ? rl[x] : RJ_EMPTY;
       ncr[j] = (x < W) ? rr_[x] : RJ_EMPTY;
+      if (WIDE) {
+        // the hash kernel's candidate rule (k_hash.h): candidate byte set, inside the margin (the row is)
+        const bool inm = x >= GPC_R && x < W - GPC_R;
+        if (inm && ncl[j] == RJ_EMPTY && cand[ro + x]) nspl |= 1u << j;
+        if (inm && ncr[j] == RJ_EMPTY && cand[ro + (long)H * W + x]) nspr |= 1u << j;
+      }
     }
   };
   fetch_row(row0);
@@ -164,12 +217,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   RJ_STAMP_INIT();
   // ---- 0. this row's codes (already in flight), table clear, next row's loads
   uint32_t cl[SPT], kl[SPT], kr[SPT];
+  uint32_t spl = 0u, spr = 0u;
   {
-    uint32_t cr[SPT];
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) {
+    for (int j = 0; j < SPT; ++j) {  // stored key = code + 1 (0 = no record in this pixel slot)
       cl[j] = ncl[j];
-      cr[j] = ncr[j];
+      kl[j] = ncl[j] + 1u;
+      kr[j] = ncr[j] + 1u;
+    }
+    if (WIDE) {
+      spl = nspl;
+      spr = nspr;
     }
     if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
@@ -177,69 +235,101 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       for (int i = tid; i < (8 * (S + 1) + 15) / 16; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid == 0) {
-      s_max_r = -1;
+      s_max_key = 0u;
       s_tail_cnt = 0;
       s_tail_minx = 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {  // stored key = code + 1 (0 = no record in this pixel slot)
-      kl[j] = cl[j] + 1u;
-      kr[j] = cr[j] + 1u;
-    }
-  }
-  __syncthreads();
-  RJ_STAMP(0);
-
-  // ---- 1. build the ordered table from the left codes
-  rj_insert_ordered<SPT>(t_key, kl, hshift, smask);
-  uint32_t max_k = 0;
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) max_k = max(max_k, kr[j]);
-  for (int o = 32; o > 0; o >>= 1) max_k = max(max_k, (uint32_t)__shfl_xor((int)max_k, o));
-  if (lane == 0 && max_k) atomicMax(&s_max_r, (int)(max_k - 1u));
-  __syncthreads();
-  RJ_STAMP(1);
-
-  // ---- 2. every record finds its code's slot (read-only) and adds (1 << 16) + x to its side
-  uint32_t hl[SPT];
-  {
-    uint32_t h0l[SPT], h0r[SPT], f0l[SPT], f0r[SPT];
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-      h0l[j] = rj_hash(kl[j], hshift);
-      h0r[j] = rj_hash(kr[j], hshift);
-    }
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {  // first probes of all records together
-      f0l[j] = 0u;
-      f0r[j] = 0u;
-      if (kl[j]) f0l[j] = t_key[h0l[j]];
-      if (kr[j]) f0r[j] = t_key[h0r[j]];
-    }
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-      const uint32_t x = (uint32_t)(j * NT + tid);
-      hl[j] = 0u;
-      if (kl[j]) {
-        hl[j] = rj_find(t_key, kl[j], f0l[j], h0l[j], smask);  // a left code is always found
-        if (atomicOr(&t_w[hl[j]], RJ_LSEEN) & RJ_LSEEN) atomicOr(&t_w[hl[j]], RJ_LDUP);  // a second left record of this code
-      }
-      if (kr[j]) {
-        const uint32_t hr = rj_find(t_key, kr[j], f0r[j], h0r[j], smask);
-        if (hr != 0xFFFFFFFFu) {
-          if (atomicOr(&t_w[hr], RJ_RSEEN) & RJ_RSEEN) atomicOr(&t_w[hr], RJ_RDUP);
-          // plain 16-bit store beside the flags: several writers only when the code is not unique, and then x is not used
-          reinterpret_cast<uint16_t*>(t_w)[2 * hr] = (uint16_t)x;
-        }
+      if (WIDE) {
+        s_sp_l = 0;
+        s_sp_r = 0;
+        s_sp_minx = 0xFFFFFFFFu;
       }
     }
   }
   // Tail quirks of the reference's merge scan concern only the largest right
   // code of the last right row that has candidates: it matches iff it occurs exactly TWICE on
   // the right (then with the first of the two in mask order) and once on the left.
-  const bool tail_row = (y == img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW]);
-  const uint32_t tail_key = (uint32_t)s_max_r + 1u;
+  const bool tail_row = (y == last_r);  // block-uniform
+  __syncthreads();
+  RJ_STAMP(0);
+
+  // ---- 1. build the ordered table from the left codes (a slot without a record inserts key 0: a no-op)
+  uint32_t h0l[SPT];
+  {
+    uint32_t old[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      // a pixel slot without a record inserts key 0 (a no-op) -- into a slot of its own: the atomics of
+      // lanes that share an address are served one after the other
+      h0l[j] = kl[j] ? rj_hash(kl[j], hshift) : ((uint32_t)(j * NT + tid) & smask);
+      old[j] = atomicMax(&t_key[h0l[j]], kl[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) rj_insert_chain(keys_lds, kl[j], old[j], h0l[j], smask);
+  }
+  if (tail_row) {  // the largest right key of this row
+    uint32_t max_k = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) max_k = max(max_k, kr[j]);
+    for (int o = 32; o > 0; o >>= 1) max_k = max(max_k, (uint32_t)__shfl_xor((int)max_k, o));
+    if (lane == 0 && max_k) atomicMax(&s_max_key, max_k);
+  }
+  if (WIDE) {  // the code without a key: count its records on either side
+    if (__ballot(spl != 0u) | __ballot(spr != 0u)) {
+      if (spl) atomicAdd(&s_sp_l, __popc(spl));
+      if (spr) {
+        atomicAdd(&s_sp_r, __popc(spr));
+        atomicMin(&s_sp_minx, (unsigned)((__ffs((int)spr) - 1) * NT + tid));
+      }
+    }
+  }
+  __syncthreads();
+  RJ_STAMP(1);
+
+  // ---- 2. every record finds its code's slot (read-only) and marks it.  The marks of a side go out
+  //      together (one LDS round trip for SPT returning atomics): a record without a slot ORs 0 into
+  //      wherever its walk stopped, which changes nothing.
+  uint32_t hl[SPT];
+  {
+    uint32_t h0r[SPT], f0l[SPT], f0r[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {  // first probes of all records together
+      h0r[j] = kr[j] ? rj_hash(kr[j], hshift) : ((uint32_t)(j * NT + tid) & smask);
+      f0l[j] = t_key[h0l[j]];
+      f0r[j] = t_key[h0r[j]];
+    }
+    uint32_t seen[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      uint32_t kk = kl[j] ? f0l[j] : 0u;
+      hl[j] = rj_find_chain(keys_lds, kl[j], kk, h0l[j], smask);  // a left code is always found
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) seen[j] = atomicOr(&t_w[hl[j]], kl[j] ? RJ_LSEEN : 0u);
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      if (kl[j] && (seen[j] & RJ_LSEEN)) atomicOr(&t_w[hl[j]], RJ_LDUP);  // a second left record of this code
+    uint32_t hr[SPT], fr = 0u;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      uint32_t kk = kr[j] ? f0r[j] : 0u;
+      hr[j] = rj_find_chain(keys_lds, kr[j], kk, h0r[j], smask);
+      if (kr[j] && kk == kr[j]) fr |= 1u << j;
+    }
+    // x goes into the zeroed low half with the same atomic: several writers only when the code is
+    // not unique on the right, and then x is not used
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      seen[j] = atomicOr(&t_w[hr[j]], ((fr >> j) & 1u) ? (RJ_RSEEN | (uint32_t)(j * NT + tid)) : 0u);
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      if (((fr >> j) & 1u) && (seen[j] & RJ_RSEEN)) atomicOr(&t_w[hr[j]], RJ_RDUP);
+  }
+  // the key the tail rule applies to; none when the row's largest right code is the key-less 0xFFFFFFFF
+  uint32_t tail_key = 0u;
+  bool tail_sp = false;
   if (tail_row) {  // block-uniform
+    tail_sp = WIDE && s_sp_r > 0;
+    tail_key = tail_sp ? 0u : s_max_key;
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
       if (kr[j] && kr[j] == tail_key) {
@@ -252,45 +342,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
   // ---- 3. decide every left candidate; the key table is dead already: it becomes the rank counters
   for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
-  bool ok[SPT];
+  uint32_t okm = 0u;  // bit j = pixel slot j is a match
   uint32_t xr[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
-    ok[j] = false;
     xr[j] = 0u;
+    bool good = false;
     if (kl[j]) {
       const uint32_t w = t_w[hl[j]];
       const bool tail = tail_row && kl[j] == tail_key;
-      bool good = !(w & RJ_LDUP) && (tail ? (s_tail_cnt == 2) : ((w & (RJ_RSEEN | RJ_RDUP)) == RJ_RSEEN));
+      good = !(w & RJ_LDUP) && (tail ? (s_tail_cnt == 2) : ((w & (RJ_RSEEN | RJ_RDUP)) == RJ_RSEEN));
       xr[j] = tail ? s_tail_minx : (w & 0xFFFFu);
-      if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
-      ok[j] = good;
+    } else if (WIDE && ((spl >> j) & 1u)) {
+      good = (s_sp_l == 1) && (s_sp_r == (tail_sp ? 2 : 1));
+      xr[j] = s_sp_minx;
     }
+    if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
+    if (good) okm |= 1u << j;
   }
-  __syncthreads();  // the accumulators are dead from here on: their LDS is reused
+  __syncthreads();  // the flag words are dead from here on: their LDS is reused
   RJ_STAMP(3);
 
   // ---- 4. output position = rank of the code among the row's matches (counting rank)
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
-    rb[j] = cl[j] >> RSHIFT;
+    rb[j] = cl[j] >> rshift;
     rs[j] = 0u;
-    if (ok[j]) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
+    if ((okm >> j) & 1u) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
   }
   __syncthreads();
   RJ_STAMP(4);
   block_exscan<SPT, NT>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b, r_cnt[NB] = number of matches
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
-    if (ok[j]) r_key[r_cnt[rb[j]] + rs[j]] = cl[j];
+    if ((okm >> j) & 1u) r_key[r_cnt[rb[j]] + rs[j]] = cl[j];
   __syncthreads();
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
   uint32_t* dst = staged + rowbase * W;
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
-    if (ok[j]) {
+    if ((okm >> j) & 1u) {
       const uint32_t s0 = r_cnt[rb[j]], e0 = r_cnt[rb[j] + 1];
       uint32_t rank = s0;
       for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cl[j]);

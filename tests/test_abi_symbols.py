@@ -54,7 +54,7 @@ def test_host_only_entry_points(lib, forest_paths, oracle):
     assert (st, fm.num_tests, fm.discarded, fm.type) == (0, 32, 288, 1)
     assert lib.gpc_hip_status_string(4).decode() == "output capacity too small"
     names = [lib.gpc_hip_kernel_name(i).decode() for i in range(lib.gpc_hip_kernel_count())]
-    assert "k_hash" in names and "k_row_match" in names
+    assert "k_hash" in names and "k_row_join" in names
 
 
 def test_no_cpu_fallback(lib):

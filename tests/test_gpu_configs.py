@@ -81,30 +81,6 @@ def test_disparity_filter_and_flat_images(ctx, oracle, forest_paths):
     assert n == 0 and ncand == (0, 0)
 
 
-def test_row_kernel_generations_agree(oracle, forest_paths):
-    """GPC_HIP_ROWMATCH selects the row kernel: join (default), bucket, lds -- identical supports."""
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-import opengpc_amd as g
-from opengpc_amd.synth import synth_pair
-ctx = g.Context(0)
-out = []
-for (W, H, fo) in [(1024, 436, "defaultZeroForest.txt"), (272, 40, "defaultTauForest.txt")]:
-    ctx.load_forest(%r + "/forests/" + fo, W, H)
-    L, R = synth_pair(W, H, 4, 17)
-    supp, n, nc, st = ctx.match_pair(L, R, g.Settings.sparsematch())
-    out.append((n, nc, int(np.frombuffer(supp.tobytes(), np.uint8).astype(np.uint64).sum()), supp.tobytes()[:64].hex()))
-print(out)
-''' % (ROOT, ROOT)
-    res = []
-    for mode in ("", "bucket", "lds"):
-        env = dict(os.environ, GPC_HIP_ROWMATCH=mode)
-        res.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True,
-                                  text=True).stdout.strip())
-    assert res[0] == res[1] == res[2] and res[0].startswith("[(")
-
-
 def test_edge_inputs(ctx, oracle, forest_paths):
     """Empty and ragged inputs: no candidates at all, candidates on one side only, the smallest
     legal image, an odd height (box writes one more row), thresholds at both ends."""
@@ -140,6 +116,85 @@ def test_edge_inputs(ctx, oracle, forest_paths):
     both(Ln, Rn, thr=255)                                # thr^2 wraps negative: everything is a candidate
 
 
-def test_very_wide_image_falls_back_to_lds_sort_kernel(ctx, oracle, forest_paths):
-    """W > 4096 exceeds the join kernel's instantiations; the LDS-sort row kernel takes over."""
-    check_pair(ctx, oracle, forest_paths["zero"], 4112, 34, 6, 21)
+@pytest.mark.parametrize("W,H", [(4112, 34), (8192, 32), (8240, 31), (16384, 30)])
+def test_very_wide_rows(ctx, oracle, forest_paths, W, H):
+    """The reference takes any width that is a multiple of 16 (filter.hpp:549).  Rows beyond 4096 px run the
+    join with 1024 threads x 8 / 16 pixel slots; beyond 8218 px the 16384-slot table (all the LDS a workgroup
+    can have) is filled past one half.  16384 is the widest image the C ABI admits."""
+    assert check_pair(ctx, oracle, forest_paths["zero"], W, H, 6, 21) > 0
+    if W == 8240:
+        check_pair(ctx, oracle, forest_paths["tau"], W, H, 7, 100, epipolar=False)
+
+
+def test_wider_than_the_abi_admits_is_refused(ctx, forest_paths):
+    import opengpc_amd as g
+    st, fm = g.read_forest(forest_paths["zero"], 16400, 32)
+    assert st == 0
+    with pytest.raises(g.GpcError) as e:
+        ctx.set_forest(fm)
+    assert e.value.status == g.capi.E_UNSUPPORTED
+
+
+def test_config4_batch_of_256_every_pair_and_shards(oracle, forest_paths):
+    """BASELINE configs[3]: 256 pairs 1024x436 (pair i: s = i, D = 8 + i mod 64), defaultZeroForest, sparsematch
+    settings, through gpc_hip_match_batch_device.  EVERY pair's candidate counts, support count and supports are
+    compared with the oracle; then the eight shards `i mod 8` (what rank r of an 8-GPU job owns, opengpc_amd.dist)
+    go through the one GPU one after the other and their union must equal the unsharded result."""
+    import torch
+    import opengpc_amd as g
+    from opengpc_amd import dist as gdist
+    from opengpc_amd.synth import synth_batch
+    from oracle.pyoracle import Oracle
+    fast = Oracle(fast=True)  # same C restatement compiled -O3 (tests/test_oracle_units.py holds it equal to the -O0 build)
+    W, H, B, N = 1024, 436, 256, 8
+    dev = torch.device("cuda", 0)
+    rc, f = fast.read_forest(forest_paths["zero"], W, H)
+    ctx = g.Context(0)
+    try:
+        ctx.load_forest(forest_paths["zero"], W, H)
+        s = g.Settings.sparsematch()
+        cap = (W - 26) * (H - 26)
+        Lh, Rh = synth_batch(W, H, list(range(B)))
+        d_L, d_R = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
+        d_out = torch.empty((B, cap, 3), dtype=torch.int32, device=dev)
+        d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_nc = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, s, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               d_nc.data_ptr())
+        ctx.synchronize()
+        counts = d_cnt.cpu().numpy()
+        ncand = d_nc.cpu().numpy()
+        whole = []
+        for i in range(B):
+            want, nl, nr = fast.match_pair(Lh[i], Rh[i], f, sparsematch_settings())
+            got = d_out[i, : int(counts[i])].cpu().numpy()
+            assert (nl, nr) == tuple(int(v) for v in ncand[i]), i
+            assert int(counts[i]) == len(want), i
+            assert np.array_equal(got[:, 0], want["x"]) and np.array_equal(got[:, 1], want["y"]), i
+            assert np.array_equal(got[:, 2].view(np.float32), want["d"]), i
+            assert np.median(want["d"]) == 8 + i % 64, i
+            whole.append(got)
+        # shard composition: rank r owns pairs r, r+8, ...; all eight shards on this one GPU, one after the other
+        seen = set()
+        per = B // N
+        for r in range(N):
+            idx = gdist.shard_indices(r, N, per)
+            assert all(gdist.owner_of(i, N) == r for i in idx)
+            seen.update(idx)
+            sel = torch.as_tensor(idx, device=dev)
+            s_L, s_R = d_L[sel].contiguous(), d_R[sel].contiguous()
+            s_out = torch.empty((per, cap, 3), dtype=torch.int32, device=dev)
+            s_cnt = torch.zeros(per, dtype=torch.int32, device=dev)
+            s_nc = torch.zeros((per, 2), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            ctx.match_batch_device(s_L.data_ptr(), s_R.data_ptr(), W, H, per, s, s_out.data_ptr(), cap,
+                                   s_cnt.data_ptr(), s_nc.data_ptr())
+            ctx.synchronize()
+            sc, sn = s_cnt.cpu().numpy(), s_nc.cpu().numpy()
+            for j, i in enumerate(idx):
+                assert sc[j] == counts[i] and tuple(sn[j]) == tuple(ncand[i]), (r, i)
+                assert np.array_equal(s_out[j, : int(sc[j])].cpu().numpy(), whole[i]), (r, i)
+        assert seen == set(range(B))
+    finally:
+        ctx.close()

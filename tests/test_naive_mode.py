@@ -103,3 +103,59 @@ def test_gpu_naive_match_pair(nctx, oracle, forest_paths, epipolar, hashtable):
         # and it is not the SSE answer
         sse, _, _ = oracle.match_pair(L, R, f, sparsematch_settings(5, 128, 0, epipolar, hashtable, False))
         assert len(sse) != len(want) or not np.array_equal(sse, want)
+
+
+def mostly_true_forest_text(tau):
+    """32 tests that hold for most pixels under the Naive predicate a > b - tau (filter.hpp:276): many
+    candidates then carry the all-ones code 0xFFFFFFFF, the one value that collides with both sentinels of
+    the HIP matchers (GPC_NOCAND in the code image, key 0 = code + 1 in the join table)."""
+    rng = np.random.default_rng(1234)
+    lines = ["4"]
+    for fern in range(4):
+        lines.append("%d l 8" % fern)
+        for t in range(8):
+            ix, iy, jx, jy = rng.integers(-13, 14, 4)
+            lines.append("%d %d %d %d %d %d" % (t, ix, iy, jx, jy, tau))
+    return "\n".join(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epipolar", [True, False])
+@pytest.mark.parametrize("hashtable", [False, True])
+def test_gpu_naive_32_tests_use_all_32_code_bits(nctx, oracle, epipolar, hashtable):
+    """SSE=OFF arithmetic with a 32-test forest: test 0 lands on bit 31 and 0xFFFFFFFF is a legal code.
+    Every matcher mode against the oracle on the stress forest (first 32 of 320 tests), wild 32-test
+    forests (|tau| up to 300) and forests whose tests mostly hold; the sweep must actually produce
+    supports whose code has bit 31 set and supports whose code is 0xFFFFFFFF."""
+    import os
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(321)
+    texts = [open(os.path.join(root, "forests", "stress16x20Forest.txt")).read(), wild_forest_text(rng),
+             wild_forest_text(rng), mostly_true_forest_text(25), mostly_true_forest_text(60), mostly_true_forest_text(300)]
+    n_bit31 = n_ones = n_total = n_ones_cand = 0
+    for (W, H, s, D) in [(96, 64, 0, 5), (272, 61, 3, 9), (1040, 44, 5, 17), (2064, 40, 2, 30)]:
+        L, R = synth_pair(W, H, s, D)
+        for text in texts:
+            st, fm = g.parse_forest(text, W, H)
+            rc, f = oracle.parse_forest_text(text, W, H)
+            assert fm.num_tests == 32 and f.num_tests == 32
+            nctx.set_forest(fm)
+            for disp_high, vtol in ((128, 0), (12, 1)):
+                want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, disp_high, vtol, epipolar, hashtable, True))
+                got, n, ncand, st = nctx.match_pair(L, R, g.Settings(5, disp_high, vtol, epipolar, hashtable, 1))
+                assert st == 0 and (nl, nr) == ncand and n == len(want), (W, H, disp_high)
+                assert np.array_equal(got, want.astype(got.dtype)), (W, H, disp_high)
+            # which codes did the supports of the last run carry?
+            sm, gr, m = oracle.preprocess_naive(L, 5)
+            codes = oracle.hash_naive(sm, m, f)
+            c = codes[want["y"], want["x"]]
+            n_total += len(c)
+            n_bit31 += int((c >> 31).sum())
+            n_ones += int((c == 0xFFFFFFFF).sum())
+            n_ones_cand += int((codes.reshape(-1)[m] == 0xFFFFFFFF).sum())
+    # candidates with the all-ones code were there to be told from non-candidates (their counts are checked above)
+    assert n_total > 0 and n_bit31 > 0 and n_ones_cand > 0
+    if epipolar and not hashtable:
+        assert n_ones > 0   # the key-less code went through the join's side channel and matched

@@ -78,3 +78,21 @@ def test_fixture_matches_the_survey_table():
     import os
     here = os.path.dirname(os.path.abspath(__file__))
     subprocess.check_call([sys.executable, os.path.join(here, "golden", "check_against_survey.py")])
+
+
+def test_fast_build_of_the_oracle_equals_the_plain_build(oracle, forest_paths, golden):
+    """libgpc_oracle_fast.so is the same gpc_oracle.c compiled -O3 -march=native; the 256-pair GPU test and the
+    bench's parity gate use it as the checker, so it is held to the plain build and to Appendix C here."""
+    from oracle.pyoracle import Oracle
+    from opengpc_amd.synth import synth_pair
+    fast = Oracle(fast=True)
+    for (W, H, s, D, fo) in [(1024, 436, 0, 24, "zero"), (1024, 436, 77, 21, "tau"), (272, 61, 5, 9, "tau")]:
+        L, R = synth_pair(W, H, s, D)
+        rc, f = oracle.read_forest(forest_paths[fo], W, H)
+        for epi in (True, False):
+            a, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(epipolar=epi))
+            b, ml, mr = fast.match_pair(L, R, f, sparsematch_settings(epipolar=epi))
+            assert (nl, nr) == (ml, mr) and np.array_equal(a, b)
+            if (W, s, fo) == (1024, 0, "zero"):
+                want = golden["cases"][1]["zero"]["epipolar" if epi else "global"]
+                assert len(b) == want["n"] and hx(supports_fnv(fast, b)) == want["fnv"]
