@@ -30,8 +30,8 @@
 #define HT_ROWS (HT_Y + 2 * GPC_R)       // 58 rows
 #define HT_COPY (HT_ROWS * HT_STRIDE)    // bytes of one (shifted) copy of the window
 
-// Passed BY VALUE as a kernel argument: every field is a 32-bit scalar the compiler keeps in
-// SGPRs (s_load from the kernarg segment), so a tap address is `lane base + SGPR`.
+// Lives in device memory (one copy per arithmetic, gpc_hip_set_forest); the hash kernel reads the
+// fields with scalar loads, so a tap address is `lane base + SGPR`.
 struct GpcForestDev {
   int32_t off[32];    // LDS DWORD offsets of a test's two taps, packed (off_a & 0xFFFF) | (off_b << 16);
                       // byte offset = (dx & 3) * HT_COPY + dy * HT_STRIDE + (dx - (dx & 3))

@@ -69,6 +69,7 @@ struct gpc_hip_ctx {
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2], hrec;
+  DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
@@ -242,11 +243,12 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   // tiles per workgroup: each CU holds 2 workgroups (67 KiB of LDS each); walking several
   // vertically adjacent tiles hides the next window's load latency, but the grid must still fill
   // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
-  const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H + HT_Y - 1) / HT_Y;
+  // tiles cover the candidate rows 13 .. H-14 only (k_hash.h)
+  const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H - 2 * GPC_R + HT_Y - 1) / HT_Y;
   int tpw = 1;
   if ((long)gx * tiles_y * nimg >= 2 * 512) {  // small launches keep one tile per workgroup (parallelism first)
     double best = 1e30;
-    for (int t = 2; t <= 9 && t <= tiles_y; ++t) {
+    for (int t = 2; t <= 16 && t <= tiles_y; ++t) {
       const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
       if (nwg < 512) break;
       const long slots = (nwg + 511) / 512 * 512;
@@ -263,7 +265,7 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
            dense ? "true" : "false", c->naive ? "true" : "false");
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, NAIVE ? c->forest_naive : c->forest, st, tpw)
+                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + (NAIVE ? 1 : 0), st, tpw)
   if (c->naive) {
     if (tau && dense) LAUNCH_HASH(true, true, true);
     else if (tau) LAUNCH_HASH(true, false, true);
@@ -610,7 +612,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1], &c->hrec};
+                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev};
   while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -766,6 +768,11 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
   f.type = fn.type = fm->type ? 1 : 0;
   c->forest = f;
   c->forest_naive = fn;
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->forest_dev, 2 * sizeof(GpcForestDev)));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // a launch in flight may still read the previous tests
+  const GpcForestDev both[2] = {f, fn};
+  HIPCHK(c, hipMemcpy(c->forest_dev.p, both, sizeof both, hipMemcpyHostToDevice));
   c->forest_w = fm->width;
   c->forest_h = fm->height;
   c->have_forest = true;
@@ -827,6 +834,8 @@ int gpc_hip_hash_codes(gpc_hip_ctx* c, const uint8_t* smooth, const uint8_t* gra
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE));
   HIPCHK(c, hipMemcpyAsync(c->smooth.p, smooth, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->grad.p, grad, n, hipMemcpyHostToDevice, c->stream));
+  // the reference's zero-filled gpcstates buffer (inference.hpp:274): the kernel writes the candidate rows only
+  HIPCHK(c, hipMemsetAsync(c->codes.p, 0, sizeof(uint32_t) * n, c->stream));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 1, true,
                (uint32_t*)c->codes.p));
   HIPCHK(c, hipMemcpyAsync(codes, c->codes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
@@ -1254,6 +1263,15 @@ extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
   HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpc::g_rj_stamps), 16 * sizeof(unsigned long long)));
   unsigned long long zero[16] = {0};
   HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_rj_stamps), zero, sizeof zero));
+  return GPC_OK;
+}
+// the same for the phases of k_hash
+extern "C" int gpc_hip_debug_hash_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
+  if (!c || !out16) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpc::g_ht_stamps), 16 * sizeof(unsigned long long)));
+  unsigned long long zero[16] = {0};
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_ht_stamps), zero, sizeof zero));
   return GPC_OK;
 }
 #endif

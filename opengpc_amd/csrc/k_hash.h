@@ -30,6 +30,32 @@
 
 namespace gpc {
 
+// Diagnostic build only (-DGPC_STAMPS, tools/stamp_profile.py): s_memtime at the phase boundaries of a tile,
+// summed per phase into a debug buffer nothing else reads.  No stamp executes in the product build.
+#ifdef GPC_STAMPS
+__device__ unsigned long long g_ht_stamps[16];
+#define HT_STAMP(i)                                                                         \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    ht_acc[i] += t_ - ht_t0;                                                                \
+    ht_t0 = t_;                                                                             \
+  } while (0)
+#define HT_STAMP_FLUSH()                                                                    \
+  if (threadIdx.x == 0 && ((blockIdx.x + blockIdx.y + blockIdx.z) & 31) == 5)               \
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ht_stamps[i_], ht_acc[i_])
+#define HT_STAMP_INIT()                                                                     \
+  unsigned long long ht_t0;                                                                 \
+  unsigned long long ht_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                  \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ht_t0)::"memory")
+#else
+#define HT_STAMP(i)
+#define HT_STAMP_INIT()
+#define HT_STAMP_FLUSH()
+#endif
+
 #define SW_H 0x80808080u
 #define SW_M 0x7F7F7F7Fu
 
@@ -104,21 +130,34 @@ __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int 
       if (TAU) b = subs_epi8x4(b, (uint32_t)(tau & 0xFF) * 0x01000100u);
       ge = swar_ge(a, b);
     }
-    plane[r] = (ge & SW_H) | ((plane[r] >> 1) & SW_M);
+    // bit 7 of every byte from ge, the rest from plane >> 1: one v_bitop3 (full rate; v_bfi / v_and_or
+    // issue at half rate on gfx950, profiles/r02_ubench2_issue_rates.txt)
+    plane[r] = __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
   }
 }
+
+// bit 7 of every byte of x that is not zero (SWAR)
+__device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & SW_M) + SW_M) | x) & SW_H; }
 
 // smooth, grad, candmap: [nimg][H][W]; codes: [nimg][H][W] u32
 // candmap == nullptr: candidate <=> grad != 0 inside the margin (preprocessImage's mask).
 // NAIVE: gpcFilterNaive / gpcFilterTauNaive (filter.hpp:237-281) -- code bits MSB-first
 // (test t on bit T-1-t), every candidate row hashed, no 16-pixel group skip.  The host passes the
 // tests in reverse order (slot u = test T-1-u) so that slot u lands on bit u.
+//
+// Tiles start at row 13: rows above it (and from H-13 on) hold no candidate, the matchers never read
+// them, and 410 candidate rows of a 436-row image are 13 tiles of 32 rows where the whole image is 14.
+// (DENSE, the parity entry point: the host zero-fills the code image first.)
+// The tests are read from memory (fp, 264 bytes every wave shares) with scalar loads, eight at a time: as
+// a by-value kernel argument the 64 words stayed live in SGPRs for the whole kernel and the allocator spilled
+// 59 of them to VGPR lanes (~100 v_readlane / v_writelane per tile).
 template <bool TAU, bool DENSE, bool NAIVE>
 __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
-                                              GpcForestDev f, int32_t* __restrict__ img_stats, int tpw) {
+                                              const GpcForestDev* __restrict__ fp, int32_t* __restrict__ img_stats,
+                                              int tpw) {
   constexpr int RPW = HT_Y / (HT_THREADS / 64);
   __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
   __shared__ int s_cnt, s_last;
@@ -148,47 +187,62 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   uint32_t* out = codes + (long)img * n;
   const int tx0 = bx * HT_X;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int x0 = tx0 + 4 * lane;
 
   if (tid == 0) { s_cnt = 0; s_last = -1; }
+
+  // bit 7 of byte j: pixel x0 + j lies inside the image and the 13-pixel margin (constant per lane)
+  uint32_t xmask = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (x0 + j >= GPC_R && x0 + j < W - GPC_R) xmask |= 0x80u << (8 * j);
 
   // A workgroup walks `tpw` vertically adjacent tiles.  The window of the NEXT tile is fetched
   // into registers (16-byte coalesced loads) before the current tile's tests run, so the global
   // latency hides behind ~7 us of VALU/LDS work; it is written to LDS (as 4 byte-shifted copies)
   // once the current tile is done.
-  constexpr int NCHUNK = HT_ROWS * (HT_STRIDE / 16);
+  constexpr int QPR = HT_STRIDE / 16;                          // 16-byte chunks per window row
+  constexpr int NCHUNK = HT_ROWS * QPR;
   constexpr int CPT = (NCHUNK + HT_THREADS - 1) / HT_THREADS;  // chunks per thread
+  // chunk -> (window row, chunk in row), byte offset inside a copy: the same for every tile
+  int crow[CPT], cdst[CPT];
+  uint32_t cflag[CPT];  // bit 0: chunk exists, bit 1: it has a right neighbour inside the window
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * HT_THREADS;
+    const int r = c / QPR, q = c - r * QPR;
+    crow[i] = r * W + q * 16 - HT_APRON + tx0;   // offset of the chunk from the window's first row
+    cdst[i] = r * HT_STRIDE + q * 16;
+    cflag[i] = (c < NCHUNK ? 1u : 0u) | (q + 1 < QPR ? 2u : 0u);
+  }
   uint4 pv[CPT];
   uint32_t pn[CPT];
   uint32_t pg[RPW];  // gradient bytes of this thread's 4 pixels in its RPW rows of the fetched tile
+  const uint32_t nbytes = (uint32_t)n;  // an image has at most 2^30 pixels (check_dims): 32-bit offsets
   auto fetch = [&](int ty0) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const int y = ty0 + (tid >> 6) * RPW + r, x = tx0 + 4 * (tid & 63);
-      pg[r] = (x < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (long)y * W + x) : 0u;
+      const int y = ty0 + wave * RPW + r;
+      pg[r] = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (uint32_t)(y * W + x0)) : 0u;
     }
+    const int base = (ty0 - GPC_R) * W;  // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * HT_THREADS;
-      const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
-      // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
-      // an image has at most 2^30 pixels (check_dims): 32-bit offsets; one unsigned compare per range check
-      const int k = (ty0 - GPC_R + r) * W + (tx0 - HT_APRON + q * 16);
+      const uint32_t k = (uint32_t)(base + crow[i]);
       pv[i] = make_uint4(0, 0, 0, 0);
       pn[i] = 0;
-      if (c < NCHUNK) {
-        if ((unsigned)k <= (unsigned)((int)n - 16)) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
-        if (q + 1 < HT_STRIDE / 16 && (unsigned)(k + 16) <= (unsigned)((int)n - 4))
-          pn[i] = *reinterpret_cast<const uint32_t*>(sm + k + 16);
+      if (cflag[i] & 1u) {  // one unsigned compare per range check (k wraps above the buffer when it is negative)
+        if (k <= nbytes - 16u) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
+        if ((cflag[i] & 2u) && k + 16u <= nbytes - 4u) pn[i] = *reinterpret_cast<const uint32_t*>(sm + (k + 16u));
       }
     }
   };
   auto stage = [&]() {  // copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * HT_THREADS;
-      if (c < NCHUNK) {
-        const int r = c / (HT_STRIDE / 16), q = c - r * (HT_STRIDE / 16);
-        uint8_t* dst = tile + r * HT_STRIDE + q * 16;
+      if (cflag[i] & 1u) {
+        uint8_t* dst = tile + cdst[i];
         const uint4 v = pv[i];
         *reinterpret_cast<uint4*>(dst) = v;
 #pragma unroll
@@ -205,50 +259,58 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   };
 
   const int tile0 = by * tpw;
-  const int ntiles = (H + HT_Y - 1) / HT_Y;
-  fetch(tile0 * HT_Y);
+  const int ntiles = (H - 2 * GPC_R + HT_Y - 1) / HT_Y;
+  HT_STAMP_INIT();
+  fetch(GPC_R + tile0 * HT_Y);
   int cnt = 0, last = -1;
+  const int T = fp->num_tests;
+  int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
+  // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
+  // becomes an immediate that no longer fits the 8-bit dword offsets of ds_read2_b32, and every pair of
+  // row reads then needs its own address add (6 adds per test instead of 2)
+  asm volatile("" : "+v"(lanebase));
+  const int n3 = max(1, min(T, 32) - 25);                     // tests that went into the last plane (T <= 25: plane empty, ~p3 = 0)
+  const uint32_t m3 = 0x01010101u * ((1u << n3) - 1u);       // n3 = 7: 0x7F7F7F7F
+  // test 8 is OR-ed into bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask)
+  const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
 #pragma unroll 1
   for (int tt = 0; tt < tpw && tile0 + tt < ntiles; ++tt) {
-  const int ty0 = (tile0 + tt) * HT_Y;
+  const int ty0 = GPC_R + (tile0 + tt) * HT_Y;
   if (tt) __syncthreads();  // every wave has finished reading the previous window
+  HT_STAMP(0);   // wait for the other waves' tests
   stage();
   uint32_t gq[RPW];
 #pragma unroll
   for (int r = 0; r < RPW; ++r) gq[r] = pg[r];
   __syncthreads();
+  HT_STAMP(1);   // window arrives (vmcnt), shifted copies written, barrier
   if (tt + 1 < tpw && tile0 + tt + 1 < ntiles) fetch(ty0 + HT_Y);
+  HT_STAMP(2);   // next window's loads issued
 
-  const int wave = tid >> 6, lane = tid & 63;
-  const int x0 = tx0 + 4 * lane;
-  const int yw = ty0 + wave * RPW;  // first row of this wave
+  const int yw = ty0 + wave * RPW;  // first row of this wave (>= 13)
 
-  // ---- per row: gradient bytes, candidate flags (bit j = pixel x0+j), group-of-16 activity
-  uint32_t candbits[RPW];
+  // ---- per row: candidate flags (bit 7 of byte j = pixel x0+j), group-of-16 activity
+  uint32_t cand8[RPW];
   bool rowdo[RPW];
   bool any = false;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int y = yw + r;
-    const bool inimg = (x0 < W) && (y < H);
-    const long k = (long)y * W + x0;
-    const uint32_t g4 = gq[r];
-    const uint32_t c4 = cm ? (inimg ? *reinterpret_cast<const uint32_t*>(cm + k) : 0u) : g4;
-    uint32_t cb = 0;
-    if (y >= GPC_R && y < H - GPC_R) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int x = x0 + j;
-        if (((c4 >> (8 * j)) & 0xFFu) && x >= GPC_R && x < W - GPC_R) cb |= 1u << j;
-      }
+    const uint32_t g4 = gq[r];  // 0 outside the image
+    uint32_t c4 = g4;
+    if (cm) c4 = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(cm + (uint32_t)(y * W + x0)) : 0u;
+    const uint32_t cb = (y < H - GPC_R) ? (swar_nonzero(c4) & xmask) : 0u;
+    // the reference skips 16-pixel groups (4 lanes here) without any gradient byte (filter.hpp:566):
+    // OR over the quad of lanes with two DPP quad permutes
+    uint32_t gany = g4;
+    if (!NAIVE) {
+      gany |= (uint32_t)__builtin_amdgcn_mov_dpp((int)gany, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+      gany |= (uint32_t)__builtin_amdgcn_mov_dpp((int)gany, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
     }
-    // the reference skips 16-pixel groups (4 lanes here) without any gradient byte (filter.hpp:566)
-    const unsigned long long gm = __ballot(g4 != 0);
-    const bool group_any = ((gm >> (lane & 60)) & 0xFull) != 0;
-    const bool rows_ok = y >= GPC_R && y < (NAIVE ? H - GPC_R : H - 15);  // gpcFilterSegment(13, height-15) :602
-    candbits[r] = cb;
-    rowdo[r] = inimg && rows_ok && (NAIVE || group_any);
-    any = any || ((DENSE && !NAIVE) ? rowdo[r] : (cb != 0 && rowdo[r]));
+    const bool rows_ok = y < (NAIVE ? H - GPC_R : H - 15);  // gpcFilterSegment(13, height-15) :602
+    cand8[r] = cb;
+    rowdo[r] = (x0 < W) && rows_ok && (NAIVE || gany != 0u);
+    any = any || ((DENSE && !NAIVE) ? rowdo[r] : (cb != 0u && rowdo[r]));
   }
 
   // ---- the tests, in the reference's byte planes: P0 = tests 0..7, (test 8), P1 = 9..16,
@@ -258,63 +320,56 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int j = 0; j < 4; ++j) code[r][j] = 0;
+  HT_STAMP(3);   // candidate flags, group activity
 
 #ifdef HT_EXP_NOCOMPUTE
   if (W < 0) {
 #else
   if (__ballot(any)) {  // wave-uniform: skip segments with nothing to hash
 #endif
-    const int T = f.num_tests;
-    int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
-    // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
-    // becomes an immediate that no longer fits the 8-bit dword offsets of ds_read2_b32, and every pair of
-    // row reads then needs its own address add (6 adds per test instead of 2)
-    asm volatile("" : "+v"(lanebase));
     uint32_t p0[RPW], p1[RPW], p2[RPW], p3[RPW], p8[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) p0[r] = p1[r] = p2[r] = p3[r] = p8[r] = ~0u;  // "ge" planes: all-ones = no bit
+#define HT_TAU(t) (TAU ? fp->tau[t] : 0)
     if (NAIVE) {
       // slot u -> bit u: four full byte planes, no special test 8
       if (T > 0) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
+        for (int t = 0; t < 8; ++t) fern_test<TAU, true, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p0);
       }
       if (T > 8) {
 #pragma unroll
-        for (int t = 8; t < 16; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
+        for (int t = 8; t < 16; ++t) fern_test<TAU, true, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p1);
       }
       if (T > 16) {
 #pragma unroll
-        for (int t = 16; t < 24; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
+        for (int t = 16; t < 24; ++t) fern_test<TAU, true, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p2);
       }
       if (T > 24) {
 #pragma unroll
-        for (int t = 24; t < 32; ++t) fern_test<TAU, true, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);
+        for (int t = 24; t < 32; ++t) fern_test<TAU, true, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p3);
       }
     } else {
       if (T > 0) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p0);
+        for (int t = 0; t < 8; ++t) fern_test<TAU, false, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p0);
       }
-      if (T > 8) fern_test<TAU, false, RPW>(tile, lanebase, f.off[8], f.tau[8], p8);
+      if (T > 8) fern_test<TAU, false, RPW>(tile, lanebase, fp->off[8], HT_TAU(8), p8);
       if (T > 9) {
 #pragma unroll
-        for (int t = 9; t < 17; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p1);
+        for (int t = 9; t < 17; ++t) fern_test<TAU, false, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p1);
       }
       if (T > 17) {
 #pragma unroll
-        for (int t = 17; t < 25; ++t) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p2);
+        for (int t = 17; t < 25; ++t) fern_test<TAU, false, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p2);
       }
       if (T > 25) {  // the last plane holds tests 25 .. min(T, 32) - 1: no padded tests here (T = 30: 5, not 7)
 #pragma unroll
         for (int t = 25; t < 32; ++t)
-          if (t < T) fern_test<TAU, false, RPW>(tile, lanebase, f.off[t], f.tau[t], p3);  // wave-uniform
+          if (t < T) fern_test<TAU, false, RPW>(tile, lanebase, fp->off[t], HT_TAU(t), p3);  // wave-uniform
       }
     }
-    const int n3 = max(1, min(T, 32) - 25);                     // tests that went into the last plane (T <= 25: plane empty, ~p3 = 0)
-    const uint32_t m3 = 0x01010101u * ((1u << n3) - 1u);       // n3 = 7: 0x7F7F7F7F
-    // test 8 is OR-ed into bit 0 unless x % 8 == 0 (64-bit-lane carry of bitMask += bitMask)
-    const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
+#undef HT_TAU
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       // planes hold "b >= a"; the code bit is its complement.  P3 saw 7 tests: one more shift.
@@ -335,6 +390,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     }
   }
 
+  HT_STAMP(4);   // tests + plane transposes
   // ---- store (16 bytes per lane and row, 1 KiB per wave and row) + statistics
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -345,15 +401,16 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t c = rowdo[r] ? code[r][j] : 0u;
-        const bool is_cand = (candbits[r] >> j) & 1u;
+        const bool is_cand = (cand8[r] >> (8 * j + 7)) & 1u;
         op[j] = DENSE ? ((NAIVE && !is_cand) ? 0u : c) : (is_cand ? c : GPC_NOCAND);
       }
-      *reinterpret_cast<uint4*>(out + (long)y * W + x0) = o;
+      *reinterpret_cast<uint4*>(out + (uint32_t)(y * W + x0)) = o;
     }
-    if (candbits[r]) { cnt += __popc(candbits[r]); last = y; }
+    if (cand8[r]) { cnt += __popc(cand8[r]); last = y; }
   }
+  HT_STAMP(5);   // code stores issued
   }  // tiles of this workgroup
-  const int lane = tid & 63;
+  HT_STAMP_FLUSH();
   if (!DENSE) {
     for (int o = 32; o > 0; o >>= 1) {
       cnt += __shfl_xor(cnt, o);

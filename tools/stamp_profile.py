@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "gpurun_out", "libgpc_hip_stamps.so")
 PHASES = ["loads+init", "insert left", "lookups+adds", "decide", "rank count", "rank scan+scatter", "rank walk+store"]
+HASH_PHASES = ["wait for other waves", "window arrives + staged + barrier", "next window's loads issued", "candidate flags",
+               "tests + transposes", "code stores issued"]
 
 
 def main():
@@ -21,7 +23,7 @@ def main():
     capi.LIB_PATH = LIB
     import opengpc_amd as g
     from opengpc_amd.synth import synth_batch
-    W, H, B = 1024, 436, 32
+    W, H, B = 1024, 436, int(sys.argv[1]) if len(sys.argv) > 1 else 32
     ctx = g.Context(0)
     ctx.load_forest(os.path.join(ROOT, "forests", "defaultZeroForest.txt"), W, H)
     L, R = synth_batch(W, H, list(range(B)))
@@ -40,6 +42,12 @@ def main():
     for i, name in enumerate(PHASES):
         print("  %-14s %6.1f %%   %8.0f ticks/wg" % (name, 100.0 * buf[i] / tot, buf[i] / nblk))
     print("  total %.0f ticks/wg" % (tot / nblk))
+    ctx.L.gpc_hip_debug_hash_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    ctx.L.gpc_hip_debug_hash_stamps(ctx.h, buf)
+    tot = sum(buf[i] for i in range(len(HASH_PHASES)))
+    print("k_hash phase shares (s_memtime ticks of thread 0 of the sampled workgroups, summed over their tiles):")
+    for i, name in enumerate(HASH_PHASES):
+        print("  %-36s %6.1f %%" % (name, 100.0 * buf[i] / max(tot, 1)))
 
 
 if __name__ == "__main__":

@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
                         "v_bitop3_b32 %5, %1, %3, %4 bitop3:0xd8\n\tv_lshrrev_b32 %6, 1, %7\n\tv_bfi_b32 %7, %9, %5, %6\n\t"
                         "v_and_b32 %0, %9, %3\n\tv_or_b32 %2, %9, %1"
                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k), "v"(k2));)
+    } else if (MODE >= 25 && MODE <= 27) {  // wide reads at addresses that are only 4-byte (25, 26, 28) or 8-byte (27) aligned
+      const uint32_t addr = (uint32_t)(uintptr_t)lds + ((tid & 63) * (MODE == 25 ? 8 : 16)) + ((it & 3) << 11) + (MODE == 27 ? 8 : 4);
+      if (MODE == 25) {
+        u32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+        REP8(LDSRD("ds_read_b64", "v"))
+        r0 += q0.x + q1.y + q2.x + q3.y + q4.x + q5.y + q6.x + q7.y;
+      } else {
+        u32x4 q0, q1, q2, q3, q4, q5, q6, q7;
+        REP8(LDSRD("ds_read_b128", "v"))
+        r0 += q0.x + q1.y + q2.z + q3.w + q4.x + q5.y + q6.z + q7.w;
+      }
     } else if (MODE >= 20 && MODE <= 23) {
       const uint32_t addr = (uint32_t)(uintptr_t)lds + ((tid & 63) * (MODE == 20 ? 4 : MODE == 21 ? 8 : MODE == 22 ? 16 : 4)) + ((it & 3) << 11);
       if (MODE == 20) {
@@ -141,7 +152,8 @@ int main() {
     {"v_pk_sub_u16", 10, 64}, {"v_fma_f32", 11, 64}, {"v_add_u32_sdwa", 12, 64}, {"v_add_u32_dpp", 13, 64}, {"v_bitop3_b32", 14, 64},
     {"v_cmp+v_addc (pairs)", 15, 64}, {"swar test mix (8 valu)", 16, 64},
     {"ds_read_b32 linear", 20, 64}, {"ds_read_b64 linear", 21, 64}, {"ds_read_b128 linear", 22, 64}, {"ds_read_u8 linear", 23, 64},
-    {"2 ds_read_b32 + 6 valu", 24, 64}};
+    {"2 ds_read_b32 + 6 valu", 24, 64}, {"ds_read_b64 addr%8==4", 25, 64}, {"ds_read_b128 addr%16==4", 26, 64},
+    {"ds_read_b128 addr%16==8", 27, 64}};
   for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     printf("== %d workgroups of 256 threads per CU (%d waves/SIMD)\n", wg_per_cu, wg_per_cu);
@@ -150,14 +162,16 @@ int main() {
       switch (c.mode) {
 #define RUN(M) case M: r = run<M>(d_out, d_cyc, blocks, iters); break;
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16)
-        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24)
+        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27)
         default: continue;
       }
       // cycles per instruction as one wave sees it, and per SIMD (divide by the waves sharing the SIMD);
       // LDS rows: per CU = per-wave figure / (4 * waves per SIMD)
       const double per_wave = r.cyc / ((double)iters * c.per_iter);
-      printf("  %-26s %8.3f ms  %7.2f cyc/instr/wave  %6.2f cyc/instr/SIMD  %6.2f cyc/instr/CU\n", c.name, r.ms, per_wave,
-             per_wave / wg_per_cu, per_wave / wg_per_cu / 4.0);
+      // the s_memtime figures are in ticks of a clock that is NOT the shader clock on this box; the wall-clock column
+      // (ns per wave-instruction per SIMD, launch overhead included) is the one to read
+      printf("  %-26s %8.3f ms  %7.2f ticks/instr/wave  %6.3f ns/instr/SIMD  %6.3f ns/instr/CU\n", c.name, r.ms, per_wave,
+             r.ms * 1e6 / ((double)iters * c.per_iter * wg_per_cu), r.ms * 1e6 / ((double)iters * c.per_iter * wg_per_cu * 4.0));
     }
   }
   return 0;
