@@ -158,10 +158,28 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const ui
                                int width, int height, int npairs, const gpc_settings* settings,
                                gpc_support* d_out, int cap_per_pair, int32_t* d_counts,
                                int32_t* d_ncand);
-/* Same from/to host memory (pinned or pageable), synchronous. */
+/* Same from/to host memory (pinned or pageable), synchronous.  With the reference's sparsematch settings
+ * (epipolar mode, sort matcher) the results cross PCIe packed (4 bytes per support, see below) and are expanded
+ * into `out` by worker threads of the library while later chunks are still on the link: settings->num_threads > 1
+ * asks for that many workers, otherwise the CPUs the process may use minus two.  The records delivered are
+ * bit-identical to the device path's. */
 int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
                         int width, int height, int npairs, const gpc_settings* settings,
                         gpc_support* out, int cap_per_pair, int32_t* counts, int32_t* ncand);
+
+/* ---- packed results ------------------------------------------------------------ */
+/* Forest::rectifiedMatch (inference.hpp:375-393) in epipolar mode emits supports row by row, so a support
+ * {x, y, float(x - xR)} (ndb::Support, buffer.hpp:91-97) is fully described by one 32-bit word x | xR << 16 plus
+ * the number of supports per row: 4 bytes instead of 12.  d_packed[npairs][cap_per_pair] receives the words in
+ * the reference's output order, d_rows[npairs][height] the per-row counts (rows outside 13 .. height-14 are not
+ * written), d_counts[npairs] the true totals.  Epipolar sort-matcher only (GPC_E_UNSUPPORTED otherwise).
+ * Asynchronous on the context's stream. */
+int gpc_hip_match_batch_device_packed(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const uint8_t* d_rawR,
+                                      int width, int height, int npairs, const gpc_settings* settings,
+                                      uint32_t* d_packed, int cap_per_pair, int32_t* d_rows,
+                                      int32_t* d_counts, int32_t* d_ncand);
+/* Host only: the first n supports of one pair from its packed words and row counts. */
+int gpc_hip_expand_packed(const uint32_t* packed, const int32_t* rows, int height, int n, gpc_support* out);
 
 /* ---- fern training: the scoring loop -------------------------- */
 /* Replaces Fern::evalSplit (Fern.hpp:209-262), Fern::markSplitSamples (Fern.hpp:271-291) and the

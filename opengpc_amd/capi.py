@@ -73,6 +73,7 @@ SYMBOLS = [
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
+    "gpc_hip_match_batch_device_packed", "gpc_hip_expand_packed",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
     "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
@@ -122,6 +123,10 @@ def load():
                                              C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.gpc_hip_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.gpc_hip_match_batch_device_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                    C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]
+    L.gpc_hip_expand_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.gpc_hip_set_kernel_timing_mask.argtypes = [C.c_void_p, C.c_uint]
     L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]
@@ -148,6 +153,17 @@ def _check(L, ctx, status, allow=()):
     if status == E_HIP and ctx:
         msg += ": " + L.gpc_hip_last_error(ctx).decode()
     raise GpcError(status, msg)
+
+
+def expand_packed(packed, rows, n):
+    """Host-side expansion of one pair's packed supports (gpc_hip_expand_packed) -> SUPPORT_DTYPE array of n records."""
+    L = load()
+    packed = np.ascontiguousarray(packed, np.uint32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    out = np.empty(max(int(n), 1), SUPPORT_DTYPE)
+    st = L.gpc_hip_expand_packed(_ptr(packed), _ptr(rows), len(rows), int(n), _ptr(out))
+    _check(L, None, st)
+    return out[:int(n)]
 
 
 def read_forest(path, width, height):
@@ -331,6 +347,13 @@ class Context:
         self._ck(self.L.gpc_hip_match_batch_device(self.h, C.c_void_p(d_rawL), C.c_void_p(d_rawR), width, height,
                                                    npairs, C.byref(settings), C.c_void_p(d_out), cap_per_pair,
                                                    C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
+
+    def match_batch_device_packed(self, d_rawL, d_rawR, width, height, npairs, settings, d_packed, cap_per_pair,
+                                  d_rows, d_counts, d_ncand=0):
+        """Packed results (x | xR << 16 per support + per-row counts) left in HBM; epipolar sort-matcher only."""
+        self._ck(self.L.gpc_hip_match_batch_device_packed(self.h, C.c_void_p(d_rawL), C.c_void_p(d_rawR), width, height,
+                                                          npairs, C.byref(settings), C.c_void_p(d_packed), cap_per_pair,
+                                                          C.c_void_p(d_rows), C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
 
     # ---- fern training: the scoring loop
     def train_set(self, triplets):

@@ -5,11 +5,18 @@
 
 #include <hip/hip_runtime.h>
 
+#include <emmintrin.h>
+#include <sched.h>
+
 #include <cctype>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gpc_device.h"
@@ -49,6 +56,68 @@ struct TimedSpan {
   int kid;
 };
 
+// where run_match puts PACKED results (k_gather_rows mode 2): words between the pairs' arrays
+struct PackedOut {
+  int32_t* rows = nullptr;
+  long packed_stride = 0, rows_stride = 0;
+};
+
+// Host threads that expand packed results (gpc_hip_expand_packed) into the caller's gpc_support arrays while the
+// next chunk is on the link.  Jobs carry the index of the staging slot they read; wait_slot() blocks until every
+// job of a slot is done, so the slot can be overwritten.
+struct ExpandJob {
+  const uint32_t* packed;
+  const int32_t* rows;
+  int H, y0, y1, first, limit;  // rows [y0, y1) of a pair whose supports start at index `first`; stop at `limit`
+  gpc_support* out;
+  int slot;
+};
+
+class ExpandPool {
+ public:
+  ~ExpandPool() { stop(); }
+  void start(int nthreads) {
+    if ((int)threads_.size() == nthreads) return;
+    stop();
+    quit_ = false;
+    for (int i = 0; i < nthreads; ++i) threads_.emplace_back([this] { run(); });
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+    threads_.clear();
+  }
+  void push(const ExpandJob& j) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      q_.push_back(j);
+      ++pending_[j.slot & 7];
+    }
+    cv_.notify_one();
+  }
+  void wait_slot(int slot) {
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return pending_[slot & 7] == 0; });
+  }
+  void wait_all() {
+    for (int s = 0; s < 8; ++s) wait_slot(s);
+  }
+  int size() const { return (int)threads_.size(); }
+
+ private:
+  void run();
+  std::vector<std::thread> threads_;
+  std::deque<ExpandJob> q_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  int pending_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool quit_ = false;
+};
+
 }  // namespace
 
 struct gpc_hip_ctx {
@@ -57,7 +126,13 @@ struct gpc_hip_ctx {
   hipStream_t stream = nullptr;
   // gpc_hip_match_batch: upload / download streams and the events that chain a chunk's stages
   hipStream_t s_in = nullptr, s_out = nullptr, s_cnt = nullptr;
-  hipEvent_t e_in[2] = {nullptr, nullptr}, e_comp[2] = {nullptr, nullptr}, e_cnt[2] = {nullptr, nullptr};
+  hipEvent_t e_in[4] = {}, e_comp[4] = {}, e_cnt[4] = {}, e_out[4] = {};
+  DevBuf packed;                  // packed results of the chunks in flight (3 slots)
+  void* h_stage = nullptr;        // page-locked landing area of packed results (4 slots)
+  size_t h_stage_cap = 0;
+  ExpandPool pool;
+  int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
+  int expand_threads = 0;         // GPC_HIP_EXPAND_THREADS (tuning)
   char err[256] = {0};
 
   bool naive = false;  // gpc_hip_set_arithmetic: the reference's SSE=OFF (*Naive) arithmetic
@@ -169,6 +244,88 @@ int check_dims(int W, int H) {
   // pixel index 30 bits
   if (W > 16384 || (long)W * H > (1l << 30)) return GPC_E_UNSUPPORTED;
   return GPC_OK;
+}
+
+// CPUs this process may really use: affinity mask and cgroup quota, at most 16
+int usable_cpus() {
+  int n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32];
+    long per = 0;
+    if (fscanf(fp, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+      const long lim = atol(q) / per;
+      if (lim >= 1 && lim < n) n = (int)lim;
+    }
+    fclose(fp);
+  }
+  return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+// Packed supports (xL | xR << 16, rows in ascending order, rows[y] of them in row y) -> ndb::Support records
+// {x, y, float(xL - xR)} (inference.hpp:384-391, buffer.hpp:91-97) for the rows [y0, y1) of one pair whose first
+// support has index `first`; stops at index `limit`.  Four records are 48 bytes = three 16-byte streaming
+// stores (no read-for-ownership of the 625 MB a 256-pair batch expands to).
+void expand_rows(const uint32_t* packed, const int32_t* rows, int y0, int y1, long first, long limit, gpc_support* out) {
+  long pos = first;
+  const uint32_t* src = packed + first;
+  const bool aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const __m128i m16 = _mm_set1_epi32(0xFFFF);
+  for (int y = y0; y < y1 && pos < limit; ++y) {
+    const long cnt = rows[y];
+    long n = cnt;
+    if (pos + n > limit) n = limit - pos;
+    long i = 0;
+    auto one = [&](uint32_t v) {
+      const int xl = (int)(v & 0xFFFFu), xr = (int)(v >> 16);
+      out[pos].x = xl;
+      out[pos].y = y;
+      out[pos].d = (float)(xl - xr);
+      ++pos;
+    };
+    if (aligned) {
+      for (; i < n && (pos & 3); ++i) one(src[i]);
+      const __m128 Y = _mm_castsi128_ps(_mm_set1_epi32(y));
+      for (; i + 4 <= n; i += 4, pos += 4) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        const __m128i xl = _mm_and_si128(v, m16);
+        const __m128 X = _mm_castsi128_ps(xl);
+        const __m128 D = _mm_cvtepi32_ps(_mm_sub_epi32(xl, _mm_srli_epi32(v, 16)));
+        const __m128 t0 = _mm_castsi128_ps(_mm_unpacklo_epi32(xl, _mm_castps_si128(Y)));  // x0 y x1 y
+        const __m128 t1 = _mm_castsi128_ps(_mm_unpackhi_epi32(xl, _mm_castps_si128(Y)));  // x2 y x3 y
+        const __m128 a = _mm_shuffle_ps(t0, _mm_shuffle_ps(D, X, _MM_SHUFFLE(1, 1, 0, 0)), _MM_SHUFFLE(2, 0, 1, 0));  // x0 y d0 x1
+        const __m128 b = _mm_shuffle_ps(_mm_shuffle_ps(Y, D, _MM_SHUFFLE(1, 1, 0, 0)), t1, _MM_SHUFFLE(1, 0, 2, 0));  // y d1 x2 y
+        const __m128 c = _mm_shuffle_ps(_mm_shuffle_ps(D, X, _MM_SHUFFLE(3, 3, 2, 2)),
+                                        _mm_shuffle_ps(Y, D, _MM_SHUFFLE(3, 3, 0, 0)), _MM_SHUFFLE(2, 0, 2, 0));      // d2 x3 y d3
+        __m128i* o = reinterpret_cast<__m128i*>(out + pos);
+        _mm_stream_si128(o, _mm_castps_si128(a));
+        _mm_stream_si128(o + 1, _mm_castps_si128(b));
+        _mm_stream_si128(o + 2, _mm_castps_si128(c));
+      }
+    }
+    for (; i < n; ++i) one(src[i]);
+    src += cnt;
+  }
+  _mm_sfence();
+}
+
+void ExpandPool::run() {
+  for (;;) {
+    ExpandJob j;
+    {
+      std::unique_lock<std::mutex> g(m_);
+      cv_.wait(g, [&] { return quit_ || !q_.empty(); });
+      if (q_.empty()) return;
+      j = q_.front();
+      q_.pop_front();
+    }
+    expand_rows(j.packed, j.rows, j.y0, j.y1, j.first, j.limit, j.out);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (--pending_[j.slot & 7] == 0) done_.notify_all();
+    }
+  }
 }
 
 int pow2_at_least(int v) {
@@ -327,9 +484,11 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
 
 // code images of npairs pairs -> supports / correspondences in d_out.
 // d_cand: the candidate bytes the hash kernel used ([2*npairs][H][W]: grad, or the scattered mask list)
+// mode 0: gpc_support, 1: gpc_correspondence, 2: packed supports (epipolar sort-match only; `po` says where)
 int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
-              void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
-  const int apply_filter = (mode == 0);
+              void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand, const PackedOut* po = nullptr) {
+  const int apply_filter = (mode != 1);
+  if (mode == 2 && (s->use_hashtable || !s->epipolar_mode || !po)) return GPC_E_UNSUPPORTED;
   if (s->use_hashtable) return run_hashtable_match(c, W, H, npairs, s, mode, d_cand, d_out, cap, d_counts, d_ncand);
   if (s->epipolar_mode) {
     CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)W * H * npairs));
@@ -379,7 +538,8 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
       const int gr = ((long)((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS) * npairs >= 2048) ? GR_ROWS : 1;
       hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + gr - 1) / gr, npairs), dim3(RM_THREADS), 0, c->stream,
                          (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
-                         cap, d_counts, (const int32_t*)c->stats.p, d_ncand, gr);
+                         cap, d_counts, (const int32_t*)c->stats.p, d_ncand, gr, po ? po->rows : nullptr,
+                         po ? po->packed_stride : 0l, po ? po->rows_stride : 0l);
       HIPCHK(c, hipGetLastError());
     }
     return GPC_OK;
@@ -599,6 +759,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (ht && atoi(ht) > 0 && atoi(ht) <= 64) c->hash_tpw = atoi(ht);
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
+  const char* ck = getenv("GPC_HIP_CHUNK");
+  if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
+  const char* et = getenv("GPC_HIP_EXPAND_THREADS");
+  if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
   const char* jn = getenv("GPC_HIP_JOIN_NT");
   if (jn && (atoi(jn) == 256 || atoi(jn) == 512 || atoi(jn) == 1024)) c->join_nt = atoi(jn);
   *out = c;
@@ -612,7 +776,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev};
+                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed};
   while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -621,12 +785,15 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
     (void)hipStreamDestroy(c->s_in);
     (void)hipStreamDestroy(c->s_out);
     (void)hipStreamDestroy(c->s_cnt);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       (void)hipEventDestroy(c->e_in[i]);
       (void)hipEventDestroy(c->e_comp[i]);
       (void)hipEventDestroy(c->e_cnt[i]);
+      (void)hipEventDestroy(c->e_out[i]);
     }
   }
+  c->pool.stop();
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GPC_OK;
@@ -929,13 +1096,27 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   return GPC_OK;
 }
 
+static int batch_streams(gpc_hip_ctx* c) {
+  if (c->s_in) return GPC_OK;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_cnt, hipStreamNonBlocking));  // the counts: never queued behind bulk copies
+  for (int i = 0; i < 4; ++i) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->e_in[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->e_comp[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->e_cnt[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->e_out[i], hipEventDisableTiming));
+  }
+  return GPC_OK;
+}
+
 // Host buffers in, supports out.  The batch goes through the device in chunks: while chunk k is matched
 // on the context's stream, chunk k+1 is uploaded on a second stream and the supports of chunk k-1 go
 // back on a third (PCIe is full duplex), so the call costs about what the longer direction of the link
 // costs -- the results' way back -- instead of upload + kernels + download one after the other.
 // The only host waits are for a chunk's counts, which say how many supports of each pair to fetch.
-int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
-                        const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
+static int match_batch_unpacked(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                                const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
   if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
   CHK(check_settings(s));
   CHK(check_dims(W, H));
@@ -948,16 +1129,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   CHK(ensure(c, c->out, sizeof(gpc_support) * (size_t)cap * npairs));
   CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
   CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
-  if (!c->s_in) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_cnt, hipStreamNonBlocking));  // the counts: never queued behind bulk copies
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(c, hipEventCreateWithFlags(&c->e_in[i], hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->e_comp[i], hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->e_cnt[i], hipEventDisableTiming));
-    }
-  }
+  CHK(batch_streams(c));
   int status = GPC_OK;
   // fetch the supports of chunk k (its counts are on their way: wait for them, then one copy per pair)
   auto collect = [&](int k) -> int {
@@ -994,6 +1166,147 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   }
   CHK(collect(nch - 1));
   HIPCHK(c, hipStreamSynchronize(c->s_out));
+  HIPCHK(c, hipStreamSynchronize(c->s_cnt));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return status;
+}
+
+int gpc_hip_match_batch_device_packed(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint8_t* d_rawR, int W, int H,
+                                      int npairs, const gpc_settings* s, uint32_t* d_packed, int cap_per_pair,
+                                      int32_t* d_rows, int32_t* d_counts, int32_t* d_ncand) {
+  if (!c || !d_rawL || !d_rawR || !d_packed || !d_rows || !d_counts || npairs <= 0 || cap_per_pair <= 0) return GPC_E_INVALID;
+  CHK(check_settings(s));
+  if (!s->epipolar_mode || s->use_hashtable) return GPC_E_UNSUPPORTED;  // rows are the unit of the packed form
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
+  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
+               (uint32_t*)c->codes.p));
+  const PackedOut po = {d_rows, (long)cap_per_pair, (long)H};
+  CHK(run_match(c, W, H, npairs, s, 2, (const uint8_t*)c->grad.p, d_packed, cap_per_pair, d_counts, d_ncand, &po));
+  return GPC_OK;
+}
+
+int gpc_hip_expand_packed(const uint32_t* packed, const int32_t* rows, int H, int n, gpc_support* out) {
+  if (!packed || !rows || !out || H < 2 * GPC_R || n < 0) return GPC_E_INVALID;
+  expand_rows(packed, rows, GPC_R, H - GPC_R, 0, n, out);
+  return GPC_OK;
+}
+
+// Host buffers in, supports out, for the epipolar sort-matcher (the reference's sparsematch settings): results
+// cross the link PACKED (4 bytes per support + the row counts instead of 12 bytes per support) and worker threads
+// expand them into the caller's ndb::Support arrays while the next chunks are uploaded, matched and downloaded.
+// Per chunk k:  upload (s_in) -> kernels (stream) -> counts (s_cnt) | download of k-1 (s_out) | expansion of k-2 (pool).
+// Device results rotate through 3 slots, the page-locked landing area through 4.
+int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                        const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
+  if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
+  CHK(check_settings(s));
+  if (!s->epipolar_mode || s->use_hashtable)
+    return match_batch_unpacked(c, rawL, rawR, W, H, npairs, s, out, cap, counts, ncand);
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  int chunk = npairs < 4 ? npairs : (npairs / 8 < 1 ? 1 : (npairs / 8 > 16 ? 16 : npairs / 8));
+  if (c->chunk_pairs > 0) chunk = c->chunk_pairs < npairs ? c->chunk_pairs : npairs;
+  const int nch = (npairs + chunk - 1) / chunk;
+  const size_t hpad = ((size_t)H + 3) & ~(size_t)3, capw = ((size_t)cap + 3) & ~(size_t)3;
+  const size_t ps = hpad + capw;  // words per pair: [row counts | packed supports]
+  CHK(ensure(c, c->raw, 2 * 2 * n * chunk));  // two slots x two sides
+  CHK(ensure(c, c->packed, sizeof(uint32_t) * 3 * ps * chunk));
+  CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
+  CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
+  const size_t stage_bytes = sizeof(uint32_t) * 4 * ps * chunk;
+  if (stage_bytes > c->h_stage_cap) {
+    c->pool.wait_all();
+    if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_stage, stage_bytes, hipHostMallocDefault));
+    c->h_stage_cap = stage_bytes;
+  }
+  CHK(batch_streams(c));
+  {  // numThreads_ of the reference's settings asks for that many workers; otherwise what the process may use
+    // (measured, 256 pairs: 3 .. 10 workers all keep up with the link -- 8.7 .. 8.9 ms per call, the link's 57 GB/s
+    // shared by both directions being the limit; 14 workers on a 16-CPU share: 10.9 ms)
+    int nt = c->expand_threads > 0 ? c->expand_threads : (s->num_threads > 1 ? s->num_threads : usable_cpus() - 2);
+    if (c->expand_threads <= 0 && s->num_threads <= 1 && nt > 8) nt = 8;
+    nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+    c->pool.start(nt);
+  }
+  uint32_t* d_pk = (uint32_t*)c->packed.p;
+  uint32_t* h_pk = (uint32_t*)c->h_stage;
+  int status = GPC_OK;
+  auto pairs_of = [&](int k) { return (k * chunk + chunk <= npairs) ? chunk : npairs - k * chunk; };
+  // the counts of chunk k are on their way: wait for them, then fetch what is valid of every pair (row counts + supports in one copy)
+  auto download = [&](int k) -> int {
+    const int p0 = k * chunk, pc = pairs_of(k);
+    HIPCHK(c, hipEventSynchronize(c->e_cnt[k & 3]));
+    c->pool.wait_slot(k & 3);  // the expansion of chunk k-4 has left this landing slot
+    for (int i = 0; i < pc; ++i) {
+      const int cnt = counts[p0 + i];
+      if (cnt > cap) status = GPC_E_CAPACITY;
+      const size_t words = hpad + (size_t)(cnt < cap ? cnt : cap);
+      HIPCHK(c, hipMemcpyAsync(h_pk + ((size_t)(k & 3) * chunk + i) * ps, d_pk + ((size_t)(k % 3) * chunk + i) * ps,
+                               sizeof(uint32_t) * words, hipMemcpyDeviceToHost, c->s_out));
+    }
+    HIPCHK(c, hipEventRecord(c->e_out[k & 3], c->s_out));
+    return GPC_OK;
+  };
+  auto expand = [&](int k) -> int {
+    const int p0 = k * chunk, pc = pairs_of(k);
+    HIPCHK(c, hipEventSynchronize(c->e_out[k & 3]));
+    const int parts = c->pool.size() >= 8 ? 4 : 2;
+    for (int i = 0; i < pc; ++i) {
+      const uint32_t* base = h_pk + ((size_t)(k & 3) * chunk + i) * ps;
+      const int32_t* rows = reinterpret_cast<const int32_t*>(base);
+      const int cnt = counts[p0 + i];
+      const long limit = cnt < cap ? cnt : cap;
+      long first = 0;
+      for (int q = 0; q < parts; ++q) {
+        const int y0 = GPC_R + (int)((long)(H - 2 * GPC_R) * q / parts), y1 = GPC_R + (int)((long)(H - 2 * GPC_R) * (q + 1) / parts);
+        if (first < limit && y1 > y0)
+          c->pool.push(ExpandJob{base + hpad, rows, H, y0, y1, (int)first, (int)limit, out + (size_t)(p0 + i) * cap, k & 3});
+        for (int y = y0; y < y1; ++y) first += rows[y];
+      }
+    }
+    return GPC_OK;
+  };
+  for (int k = 0; k < nch; ++k) {
+    const int ev = k & 3, p0 = k * chunk, pc = pairs_of(k);
+    uint8_t* d_l = (uint8_t*)c->raw.p + (size_t)(k & 1) * 2 * n * chunk;
+    uint8_t* d_r = d_l + n * chunk;
+    if (k >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->e_comp[(k - 2) & 3], 0));  // chunk k-2 has read this slot
+    HIPCHK(c, hipMemcpyAsync(d_l, rawL + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipMemcpyAsync(d_r, rawR + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipEventRecord(c->e_in[ev], c->s_in));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_in[ev], 0));
+    if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_out[(k - 3) & 3], 0));  // chunk k-3 has left this result slot
+    uint32_t* slot = d_pk + (size_t)(k % 3) * chunk * ps;
+    CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * pc));
+    CHK(run_preprocess(c, d_l, d_r, W, H, pc, 2, s->gradient_threshold));
+    CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * pc, false, (uint32_t*)c->codes.p));
+    const PackedOut po = {reinterpret_cast<int32_t*>(slot), (long)ps, (long)ps};
+    CHK(run_match(c, W, H, pc, s, 2, (const uint8_t*)c->grad.p, slot + hpad, cap, (int32_t*)c->counts.p + p0,
+                  (int32_t*)c->ncand.p + 2 * p0, &po));
+    HIPCHK(c, hipEventRecord(c->e_comp[ev], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->s_cnt, c->e_comp[ev], 0));
+    HIPCHK(c, hipMemcpyAsync(counts + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
+    if (ncand)
+      HIPCHK(c, hipMemcpyAsync(ncand + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc,
+                               hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipEventRecord(c->e_cnt[ev], c->s_cnt));
+    if (k >= 1) CHK(download(k - 1));
+    if (k >= 2) CHK(expand(k - 2));
+  }
+  CHK(download(nch - 1));
+  if (nch >= 2) CHK(expand(nch - 2));
+  CHK(expand(nch - 1));
+  c->pool.wait_all();
   HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return status;

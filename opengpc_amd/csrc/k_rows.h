@@ -24,7 +24,10 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 }
 
 // Expands the staged rows into the caller's array, rows in ascending order.
-// mode 0: gpc_support {x, y, float(xL-xR)}; mode 1: gpc_correspondence {xL, y, xR, y}
+// mode 0: gpc_support {x, y, float(xL-xR)}; mode 1: gpc_correspondence {xL, y, xR, y};
+// mode 2: PACKED -- the staged words (xL | xR << 16) themselves, made contiguous, plus a copy of the pair's
+//         row counts in rows_out[pair * rows_stride + y]: 4 bytes per support instead of 12 for results that leave over PCIe
+//         (gpc_hip_match_batch expands them on the host, gpc_hip_expand_packed).
 // grid: (ceil((H - 26) / rows_per_wg), npairs).  A workgroup expands rows_per_wg (GR_ROWS; 1 for launches too
 // small to fill the device otherwise) consecutive rows: one block-wide
 // sum of the earlier rows' counts for the first of them, a running offset for the rest (one row per
@@ -35,11 +38,12 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
     const uint32_t* __restrict__ staged, const int32_t* __restrict__ rowcnt, int W, int H, int mode,
     void* __restrict__ out, int cap, int32_t* __restrict__ counts, const int32_t* __restrict__ img_stats,
-    int32_t* __restrict__ ncand, int rows_per_wg) {
+    int32_t* __restrict__ ncand, int rows_per_wg, int32_t* __restrict__ rows_out, long packed_stride, long rows_stride) {
   const int y0 = GPC_R + blockIdx.x * rows_per_wg, pair = blockIdx.y;
   const int32_t* rc = rowcnt + (long)pair * H;
   int off = block_prefix_rows(rc, GPC_R, y0);
   const int yend = min(y0 + rows_per_wg, H - GPC_R);
+  if (mode == 2 && (int)threadIdx.x < yend - y0) rows_out[pair * rows_stride + y0 + threadIdx.x] = rc[y0 + threadIdx.x];
   for (int y = y0; y < yend; ++y) {
     const int cnt = rc[y];
     const uint32_t* src = staged + ((long)pair * H + y) * W;
@@ -53,6 +57,13 @@ __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
         o[pos * 3 + 0] = xl;
         o[pos * 3 + 1] = y;
         o[pos * 3 + 2] = __float_as_uint((float)(xl - xr));
+      }
+    } else if (mode == 2) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out) + pair * packed_stride;  // packed_stride: words between pairs
+      for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
+        const int pos = off + i;
+        if (pos >= cap) break;
+        o[pos] = src[i];
       }
     } else {
       int4* o = reinterpret_cast<int4*>(out) + (long)pair * cap;

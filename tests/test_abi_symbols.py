@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,3 +76,26 @@ def test_product_never_imports_the_oracle():
                 if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
                     text = open(os.path.join(dirpath, fn), errors="ignore").read()
                     assert "pyoracle" not in text and "gpc_oracle" not in text and "libgpc_ref" not in text, fn
+
+
+def test_expand_packed_is_host_only_and_exact(lib):
+    """gpc_hip_expand_packed: x | xR << 16 words + per-row counts -> ndb::Support records {x, y, float(x - xR)}
+    (inference.hpp:384-391).  Host code, so it runs without a GPU; every alignment of the output and every
+    tail length of the 4-record streaming-store groups is exercised."""
+    import opengpc_amd as g
+    rng = np.random.default_rng(5)
+    H = 61
+    for trial in range(30):
+        rows = np.zeros(H, np.int32)
+        rows[13:H - 13] = rng.integers(0, 9, H - 26) if trial % 3 else rng.integers(0, 300, H - 26)
+        rows[:13] = -7            # never read
+        n_all = int(rows[13:H - 13].sum())
+        xl = rng.integers(13, 4000, n_all).astype(np.uint32)
+        xr = rng.integers(0, 4096, n_all).astype(np.uint32)
+        packed = xl | (xr << 16)
+        y = np.repeat(np.arange(13, H - 13), rows[13:H - 13])
+        for n in sorted({n_all, max(n_all - 5, 0), n_all // 2, min(3, n_all), 0}):
+            got = g.capi.expand_packed(packed, rows, n)
+            assert len(got) == n
+            assert np.array_equal(got["x"], xl[:n].astype(np.int32)) and np.array_equal(got["y"], y[:n])
+            assert np.array_equal(got["d"], (xl[:n].astype(np.int64) - xr[:n].astype(np.int64)).astype(np.float32))

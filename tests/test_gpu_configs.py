@@ -198,3 +198,72 @@ def test_config4_batch_of_256_every_pair_and_shards(oracle, forest_paths):
         assert seen == set(range(B))
     finally:
         ctx.close()
+
+
+def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
+    """gpc_hip_match_batch_device_packed + gpc_hip_expand_packed == gpc_hip_match_batch_device, and the host entry
+    point gpc_hip_match_batch (which moves packed results over PCIe and expands them on worker threads) delivers the
+    same records: several shapes incl. ragged widths and an odd height, both forests, a tight disparity filter,
+    capacities that cut pairs short, chunk sizes that leave a ragged last chunk."""
+    import torch
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    ctx = g.Context(0)
+    try:
+        for (W, H, P, fo, disp) in [(1024, 436, 11, "zero", 128), (272, 61, 37, "tau", 128), (528, 41, 5, "tau", 9),
+                                    (2064, 36, 3, "zero", 128), (48, 30, 2, "zero", 128)]:
+            ctx.load_forest(forest_paths[fo], W, H)
+            s = g.Settings(5, disp, 0, True, False, 1)
+            Lh, Rh = synth_batch(W, H, [3 * i + 1 for i in range(P)])
+            d_L, d_R = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
+            cap = (W - 26) * (H - 26)
+            d_out = torch.zeros((P, cap, 3), dtype=torch.int32, device=dev)
+            d_cnt = torch.zeros(P, dtype=torch.int32, device=dev)
+            d_nc = torch.zeros((P, 2), dtype=torch.int32, device=dev)
+            d_pk = torch.zeros((P, cap), dtype=torch.int32, device=dev)
+            d_rows = torch.zeros((P, H), dtype=torch.int32, device=dev)
+            d_cnt2 = torch.zeros(P, dtype=torch.int32, device=dev)
+            d_nc2 = torch.zeros((P, 2), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, P, s, d_out.data_ptr(), cap, d_cnt.data_ptr(), d_nc.data_ptr())
+            ctx.match_batch_device_packed(d_L.data_ptr(), d_R.data_ptr(), W, H, P, s, d_pk.data_ptr(), cap, d_rows.data_ptr(),
+                                          d_cnt2.data_ptr(), d_nc2.data_ptr())
+            ctx.synchronize()
+            cnt = d_cnt.cpu().numpy()
+            assert np.array_equal(cnt, d_cnt2.cpu().numpy()) and torch.equal(d_nc, d_nc2) and cnt.sum() > 0
+            pk, rows = d_pk.cpu().numpy().view(np.uint32), d_rows.cpu().numpy()
+            ref = []
+            for i in range(P):
+                want = d_out[i, : int(cnt[i])].cpu().numpy()
+                assert int(rows[i, 13:H - 13].sum()) == cnt[i]
+                got = g.capi.expand_packed(pk[i], rows[i], int(cnt[i]))
+                assert np.array_equal(got["x"], want[:, 0]) and np.array_equal(got["y"], want[:, 1])
+                assert np.array_equal(got["d"], want[:, 2].view(np.float32))
+                ref.append(got)
+            # the host entry point: pageable and page-locked buffers, full and short capacities
+            for hcap in (cap, max(int(cnt.max()) - 7, 1), 100):
+                for pinned in (False, True):
+                    out = ctx.pinned_empty((P, hcap), g.SUPPORT_DTYPE) if pinned else None
+                    o, c2, n2, st = ctx.match_batch(Lh, Rh, s, hcap, out=out)
+                    assert np.array_equal(c2, cnt) and np.array_equal(n2, d_nc.cpu().numpy())
+                    assert st == (g.capi.E_CAPACITY if (cnt > hcap).any() else 0)
+                    for i in range(P):
+                        k = min(int(cnt[i]), hcap)
+                        assert np.array_equal(o[i, :k], ref[i][:k]), (W, H, hcap, pinned, i)
+    finally:
+        ctx.close()
+
+
+def test_packed_results_are_refused_outside_the_epipolar_sort_matcher(ctx, forest_paths):
+    import torch
+    import opengpc_amd as g
+    W, H = 96, 64
+    ctx.load_forest(forest_paths["zero"], W, H)
+    z = torch.zeros((1, H, W), dtype=torch.uint8, device="cuda:0")
+    buf = torch.zeros((1, 4096), dtype=torch.int32, device="cuda:0")
+    for s in (g.Settings(5, 128, 0, False, False, 1), g.Settings(5, 128, 0, True, True, 1)):
+        with pytest.raises(g.GpcError) as e:
+            ctx.match_batch_device_packed(z.data_ptr(), z.data_ptr(), W, H, 1, s, buf.data_ptr(), 4096, buf.data_ptr(),
+                                          buf.data_ptr(), 0)
+        assert e.value.status == g.capi.E_UNSUPPORTED
