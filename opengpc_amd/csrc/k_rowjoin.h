@@ -381,6 +381,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
   uint32_t* dst = staged + rowbase * W;
+  // (writing the matches that are alone in their bucket -- most of them -- straight from the scan and walking only
+  // the shared buckets measured slower on the same box: 553 vs 546 us per 256 pairs)
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) {

@@ -3,6 +3,7 @@
 //   host_api_check write_gray <w> <h> <out.png>  (pixel = (x*3 + y*7) & 0xFF)
 //   host_api_check write_rgb <w> <h> <out.png>   (r = x, g = y, b = x ^ y, all & 0xFF)
 //   host_api_check vis <w> <h> <out.png>         supports on a diagonal, d = x/2
+//   host_api_check ramp <out.raw>                disparityColor for d = -4.0, -3.5 .. 260.0 as RGB bytes (529 x 3)
 //   host_api_check settings                      prints InferenceSettings defaults and builder result
 //   host_api_check clear <w> <h> <out.raw>       clearBoundary on an all-255 buffer of visible width w
 #include <cstdio>
@@ -51,6 +52,16 @@ int main(int argc, char** argv) {
       fclose(f);
       printf("RESULT %d %d\n", b.cols(), b.rows());
     }
+    return 0;
+  }
+  if (cmd == "ramp" && argc == 3) {
+    FILE* f = fopen(argv[2], "wb");
+    for (int i = -8; i <= 520; ++i) {
+      const ndb::RGBColor c = ndb::disparityColor(0.5f * (float)i);
+      const uint8_t px[3] = {c.r, c.g, c.b};
+      fwrite(px, 1, 3, f);
+    }
+    fclose(f);
     return 0;
   }
   if (cmd == "settings") {

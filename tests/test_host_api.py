@@ -107,6 +107,48 @@ def test_png_write_and_visualisation(check_bin, tmp_path):
     assert tuple(v[0, 0]) == (0, 0, 255) and v[40, 40, 0] > v[2, 2, 0]  # ramp starts blue, reddens
 
 
+def kitti_ramp(d):
+    """numpy float32 restatement of the colour ramp of ndb::getDisparityVisualization (reference
+    lib/gpc/buffer.hpp:958-1010), operation by operation in float32 with no fused multiply-add (a reference
+    binary built with -march=core-avx2 may contract `w * a + (1 - w) * b` and differ in a last bit; the
+    restatement pins this repository's header to the source's unfused arithmetic).  d: float array -> uint8 [n][3]."""
+    f = np.float32
+    ramp = np.array([[0, 0, 1, 185], [1, 0, 0, 114], [1, 0, 1, 174], [0, 1, 0, 114], [0, 1, 1, 185], [1, 1, 0, 114],
+                     [1, 1, 1, 0], [0, 0, 0, 114]], np.float32)
+    total = f(0)
+    for i in range(8):                       # :964-967
+        total = f(total + ramp[i, 3])
+    weights, cumsum = np.zeros(8, np.float32), np.zeros(8, np.float32)
+    for i in range(7):                       # :972-975
+        weights[i] = f(total / ramp[i, 3])
+        cumsum[i + 1] = f(cumsum[i] + f(ramp[i, 3] / total))
+    out = np.zeros((len(d), 3), np.uint8)
+    for k, disp in enumerate(np.asarray(d, np.float32)):
+        value = max(f(0), min(f(0.8), f(f(disp - f(0)) / f(f(128) - f(0)))))   # :985-988
+        b = 7
+        for j in range(7):                   # :991-995
+            if value < cumsum[j + 1]:
+                b = j
+                break
+        w = f(f(1) - f(f(value - cumsum[b]) * weights[b]))                      # :999
+        for ch in range(3):                  # :1000-1008: float -> uint8 truncates
+            out[k, ch] = int(f(f(f(w * ramp[b, ch]) + f(f(f(1) - w) * ramp[b + 1, ch])) * f(255)))
+    return out
+
+
+def test_disparity_colour_ramp_over_every_disparity(check_bin, tmp_path):
+    """disparityColor (include/gpc/buffer.hpp) == the restatement for every half-integer disparity from -4 to 260:
+    all 129 integer disparities the default dispHigh admits, the clamp at 0.8 (d >= 102.4) and negative values."""
+    p = str(tmp_path / "ramp.raw")
+    run(check_bin, "ramp", p)
+    got = np.fromfile(p, np.uint8).reshape(-1, 3)
+    d = 0.5 * np.arange(-8, 521, dtype=np.float32)
+    assert len(got) == len(d) == 529
+    want = kitti_ramp(d)
+    assert np.array_equal(got, want), np.flatnonzero(np.any(got != want, axis=1))[:10]
+    assert tuple(got[8]) == (0, 0, 255) and len({tuple(c) for c in got[8:8 + 2 * 129:2]}) > 90   # d = 0 is blue; the ramp moves
+
+
 def test_clear_boundary(check_bin, tmp_path, oracle):
     raw = str(tmp_path / "cb.raw")
     out = run(check_bin, "clear", "48", "20", raw)
@@ -152,6 +194,18 @@ def test_sparsematch_sample(tmp_path, golden, forest_paths, fused):
     assert int(m.group(3)) == c["zero"]["epipolar"]["n"]
     vis = np.array(Image.open(str(tmp_path / "disparity.png")))
     assert vis.shape == (c["H"], c["W"], 3)
+    # every pixel of disparity.png: the gray left image with each support painted, in output order, in its ramp colour
+    # (getDisparityVisualization + writePNGRGB, buffer.hpp:949-1014, 395-474); supports from the oracle
+    from oracle.pyoracle import Oracle, sparsematch_settings
+    o = Oracle()
+    rc, f = o.read_forest(forest_paths["zero"], c["W"], c["H"])
+    supp, nl, nr = o.match_pair(L, R, f, sparsematch_settings())
+    want = np.repeat(L[:, :, None], 3, axis=2)
+    ds = np.unique(supp["d"])
+    lut = dict(zip(ds.tolist(), kitti_ramp(ds)))
+    for s_ in supp:
+        want[s_["y"], s_["x"]] = lut[float(s_["d"])]
+    assert np.array_equal(vis, want)
     changed = np.any(vis != L[:, :, None], axis=2)
     assert 0 < changed.sum() <= c["zero"]["epipolar"]["n"]
 

@@ -4,6 +4,8 @@ oracle standing in for the GPU in this test only), and the gathered counters / t
 reduction equal the single-process result."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -94,3 +96,25 @@ def test_single_process_helpers():
     assert stats.shape == (1, 4)
     job = gdist.reduce_job(stats, 10, 2 * 1024 * 436)
     assert job["pairs_per_s"] == pytest.approx(640.0)
+
+
+@pytest.mark.gpu
+def test_rccl_path_rehearsal_on_one_gpu(tmp_path):
+    """bench.py with GPC_FORCE_DIST=1 at world size 1: torch.distributed is initialised with backend "nccl"
+    (RCCL), the timed windows run between RCCL barriers and the per-rank row goes through all_gather on the
+    device -- the N > 1 code path end to end, on the one GPU a test box has."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GPC_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--windows", "3", "--batch", "16", "--verify-pairs", "3", "--no-cpu-baseline", "--no-extras"],
+                         env=env, check=True, capture_output=True, text=True, timeout=600).stdout
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["windows"]["count"] == 3
+    assert line["verified_vs_oracle"] is True and line["verified_pairs"] == 3
+    assert line["value"] > 1000 and line["config"]["parallelism"] == "pairs-dp1"
+    assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["kernel"].startswith("gpc::k_")
