@@ -349,33 +349,51 @@ def main():
             roofline["copy_measured_GBs"] = round(copy_gbs, 1)
 
         # ---- the reference's own timed region: raw pairs in (pinned) host memory -> gpc_support arrays in host
-        #      memory, one synchronous gpc_hip_match_batch call per batch (H2D + kernels + D2H, overlapped in chunks)
+        #      memory, one synchronous gpc_hip_match_batch call per batch (H2D + kernels + packed D2H + expansion on
+        #      worker threads, overlapped in chunks).  The host API has no torch dependency, and a process that has
+        #      imported torch runs every HIP library on the ROCm runtime bundled with the torch wheel (an older one
+        #      than the /opt/rocm this library is built against; its copies are slower).  So the call is timed in a
+        #      child process without torch -- the C++ caller's situation -- and, for the record, in this process too.
         pcie = None
         if world == 1 and not args.no_extras:
+            import subprocess
+            import zlib
+            try:
+                outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pcie_inclusive.py"), "--one", str(B), str(W),
+                                       str(H), args.forest], check=True, capture_output=True, text=True, timeout=300).stdout
+                pcie = json.loads(outp.strip().splitlines()[-1])
+                ch_counts = np.asarray(pcie.pop("counts"), np.int64)
+                crc = pcie.pop("crc32")
+                same = bool(pcie["status"] == 0 and np.array_equal(ch_counts, counts))
+                for j in (0, B // 2, B - 1):   # the device path's 12-byte records of three pairs, byte for byte
+                    same = same and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
+                pcie["identical_to_device_path"] = same
+                pcie["measured_in"] = "child process without torch (the library's own ROCm runtime)"
+                pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 7 calls"
+            except Exception as e:  # the headline does not depend on it
+                pcie = None
+                print("bench.py: pcie_inclusive child failed: %r" % (e,), file=sys.stderr)
+            # the same call inside this (torch) process
             capi_cap = 300000
             Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
             Lp[:] = Lh
             Rp[:] = Rh
-            outp = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
+            outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
             for _ in range(2):
-                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outp)
+                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
             tt = []
-            for _ in range(7):
+            for _ in range(5):
                 t0 = time.perf_counter()
-                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outp)
+                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
                 tt.append(time.perf_counter() - t0)
             tt.sort()
-            dt = tt[len(tt) // 2]
-            same = bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts))
-            for j in (0, B // 2, B - 1):
-                dj = d_out[j, : int(counts[j])].cpu().numpy()
-                same = same and bool(np.array_equal(o_[j, : int(c_[j])]["x"], dj[:, 0])
-                                     and np.array_equal(o_[j, : int(c_[j])]["d"], dj[:, 2].view(np.float32)))
-            pcie = {"value": round(2.0 * W * H * B / dt / 1e6, 1), "unit": "Mpix/s", "ms_per_call": round(dt * 1e3, 3),
-                    "pairs_per_call": B, "host_buffers": "page-locked (gpc_hip_host_alloc)",
-                    "bytes_in": int(Lh.nbytes + Rh.nbytes), "bytes_out": int(c_.sum()) * 12,
-                    "identical_to_device_path": same,
-                    "timed_region": "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 7 calls"}
+            here = {"ms_per_call": round(tt[len(tt) // 2] * 1e3, 3), "value": round(2.0 * W * H * B / tt[len(tt) // 2] / 1e6, 1),
+                    "identical_to_device_path": bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts)),
+                    "note": "same call from this process, whose HIP runtime is the one bundled with torch"}
+            if pcie is None:
+                pcie = dict(here, unit="Mpix/s", pairs_per_call=B, measured_in="this process (torch's bundled ROCm runtime)")
+            else:
+                pcie["in_this_process"] = here
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
