@@ -232,7 +232,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
-      for (int i = tid; i < (8 * (S + 1) + 15) / 16; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+      // the zeros are made HERE: as a plain constant the compiler keeps them in four registers across the whole row
+      // and, at 64 VGPRs, spills them to scratch (one 16-byte store + load per thread and row)
+      uint32_t z0;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
+      const uint4 zero = make_uint4(z0, z0, z0, z0);
+      for (int i = tid; i < (8 * (S + 1) + 15) / 16; i += NT) z[i] = zero;
     }
     if (tid == 0) {
       s_max_key = 0u;
@@ -364,6 +369,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   RJ_STAMP(3);
 
   // ---- 4. output position = rank of the code among the row's matches (counting rank)
+  // Measured on one box and NOT adopted (546 / 514 us per 256 pairs as it stands):
+  //   * matches alone in their bucket written straight from the scan, only shared buckets walked: 553 us;
+  //   * matches first appended to a dense list (a wave reserving its stretch with one atomic) and ranked from
+  //     there, one match per thread, with 16-bit counters beside the table: 522 us.
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
@@ -381,8 +390,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
   uint32_t* dst = staged + rowbase * W;
-  // (writing the matches that are alone in their bucket -- most of them -- straight from the scan and walking only
-  // the shared buckets measured slower on the same box: 553 vs 546 us per 256 pairs)
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) {
@@ -391,12 +398,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cl[j]);
       dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
     }
+  if (tid == 0) rowcnt[rowbase] = (int32_t)r_cnt[NB];
 #ifdef GPC_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RJ_STAMP(6);
   RJ_STAMP_FLUSH();
-  if (tid == 0) rowcnt[rowbase] = (int32_t)r_cnt[NB];
   if (ri + 1 < rpw && y + 1 < H - GPC_R) __syncthreads();  // the table is cleared again for the next row
   }  // rows of this workgroup
 }

@@ -27,8 +27,25 @@ def main():
     s.epipolar_mode = int(epipolar)
     s.use_hashtable = int(os.environ.get("GPC_PROF_HASHTABLE") is not None)
     cap = (W - 26) * (H - 26)
+    # device-resident launches exactly like bench.py's (whole batch per launch, 12-byte supports left in HBM);
+    # device memory through the HIP runtime the library itself is linked against
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        return p
+    d_L, d_R = dmalloc(L.nbytes), dmalloc(R.nbytes)
+    d_out, d_cnt, d_nc = dmalloc(B * cap * 12), dmalloc(B * 4), dmalloc(B * 8)
+    assert hip.hipMemcpy(d_L, C.c_void_p(L.ctypes.data), C.c_size_t(L.nbytes), 1) == 0
+    assert hip.hipMemcpy(d_R, C.c_void_p(R.ctypes.data), C.c_size_t(R.nbytes), 1) == 0
     for _ in range(steps):
-        out, counts, ncand, st = ctx.match_batch(L, R, s, cap)
+        ctx.match_batch_device(d_L.value, d_R.value, W, H, B, s, d_out.value, cap, d_cnt.value, d_nc.value)
+    ctx.synchronize()
+    counts, ncand = np.empty(B, np.int32), np.empty((B, 2), np.int32)
+    assert hip.hipMemcpy(C.c_void_p(counts.ctypes.data), d_cnt, C.c_size_t(B * 4), 2) == 0
+    assert hip.hipMemcpy(C.c_void_p(ncand.ctypes.data), d_nc, C.c_size_t(B * 8), 2) == 0
     print("steps", steps, "pairs", B, "supports/pair", counts.mean(), "cand/pair", ncand.sum(1).mean())
     ctx.close()
 
