@@ -59,7 +59,8 @@ struct TimedSpan {
 // where run_match puts PACKED results (k_gather_rows mode 2): words between the pairs' arrays
 struct PackedOut {
   int32_t* rows = nullptr;
-  long packed_stride = 0, rows_stride = 0;
+  long packed_stride = 0, rows_stride = 0;  // words between the pairs' arrays
+  int32_t* totals = nullptr;                // non-null: scratch [npairs]; the pairs' records are then written back to back
 };
 
 // Host threads that expand packed results (gpc_hip_expand_packed) into the caller's gpc_support arrays while the
@@ -130,6 +131,8 @@ struct gpc_hip_ctx {
   DevBuf packed;                  // packed results of the chunks in flight (3 slots)
   void* h_stage = nullptr;        // page-locked landing area of packed results (4 slots)
   size_t h_stage_cap = 0;
+  int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
+  size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
   int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
   int expand_threads = 0;         // GPC_HIP_EXPAND_THREADS (tuning)
@@ -535,11 +538,15 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     {
       Timed t(c, KID_GATHER_ROWS);
       snprintf(c->launch_name[KID_GATHER_ROWS], sizeof c->launch_name[0], "gpc::k_gather_rows");
+      if (po && po->totals)
+        hipLaunchKernelGGL(gpc::k_pair_totals, dim3(npairs), dim3(RM_THREADS), 0, c->stream, (const int32_t*)c->rowcnt.p, H,
+                           po->totals);
       const int gr = ((long)((H - 2 * GPC_R + GR_ROWS - 1) / GR_ROWS) * npairs >= 2048) ? GR_ROWS : 1;
       hipLaunchKernelGGL(gpc::k_gather_rows, dim3((H - 2 * GPC_R + gr - 1) / gr, npairs), dim3(RM_THREADS), 0, c->stream,
                          (const uint32_t*)c->staged.p, (const int32_t*)c->rowcnt.p, W, H, mode, d_out,
                          cap, d_counts, (const int32_t*)c->stats.p, d_ncand, gr, po ? po->rows : nullptr,
-                         po ? po->packed_stride : 0l, po ? po->rows_stride : 0l);
+                         po ? po->packed_stride : 0l, po ? po->rows_stride : 0l,
+                         po ? (const int32_t*)po->totals : (const int32_t*)nullptr);
       HIPCHK(c, hipGetLastError());
     }
     return GPC_OK;
@@ -794,6 +801,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   }
   c->pool.stop();
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GPC_OK;
@@ -1214,13 +1222,17 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   int chunk = npairs < 4 ? npairs : (npairs / 8 < 1 ? 1 : (npairs / 8 > 16 ? 16 : npairs / 8));
   if (c->chunk_pairs > 0) chunk = c->chunk_pairs < npairs ? c->chunk_pairs : npairs;
   const int nch = (npairs + chunk - 1) / chunk;
-  const size_t hpad = ((size_t)H + 3) & ~(size_t)3, capw = ((size_t)cap + 3) & ~(size_t)3;
-  const size_t ps = hpad + capw;  // words per pair: [row counts | packed supports]
+  // (three-byte records x | (x - xR + dispHigh) << xbits were tried for the link: byte stores on the device and a
+  // byte shuffle on the host made the call slower, 7.5 vs 6.2 ms per 256 pairs; the link is not the limit any more)
+  const size_t rec = 4;
+  const size_t hpad = ((size_t)H + 3) & ~(size_t)3;
+  // a chunk's results: [row counts: chunk x hpad words | the pairs' records back to back | pad] -- one copy per chunk
+  const size_t cb = 4 * hpad * chunk + ((rec * (size_t)cap * chunk + 15) & ~(size_t)15) + 16;
   CHK(ensure(c, c->raw, 2 * 2 * n * chunk));  // two slots x two sides
-  CHK(ensure(c, c->packed, sizeof(uint32_t) * 3 * ps * chunk));
+  CHK(ensure(c, c->packed, 3 * cb + sizeof(int32_t) * 3 * chunk));
   CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
   CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
-  const size_t stage_bytes = sizeof(uint32_t) * 4 * ps * chunk;
+  const size_t stage_bytes = 4 * cb;
   if (stage_bytes > c->h_stage_cap) {
     c->pool.wait_all();
     if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
@@ -1229,6 +1241,15 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     HIPCHK(c, hipHostMalloc(&c->h_stage, stage_bytes, hipHostMallocDefault));
     c->h_stage_cap = stage_bytes;
   }
+  if ((size_t)npairs * 3 > c->h_cnt_cap) {
+    if (c->h_cnt) HIPCHK(c, hipHostFree(c->h_cnt));
+    c->h_cnt = nullptr;
+    c->h_cnt_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, sizeof(int32_t) * 3 * (size_t)npairs, hipHostMallocDefault));
+    c->h_cnt_cap = (size_t)npairs * 3;
+  }
+  int32_t* hc = c->h_cnt;               // counts
+  int32_t* hn = c->h_cnt + npairs;      // candidate counts
   CHK(batch_streams(c));
   {  // numThreads_ of the reference's settings asks for that many workers; otherwise what the process may use
     // (measured, 256 pairs: 3 .. 10 workers all keep up with the link -- 8.7 .. 8.9 ms per call, the link's 57 GB/s
@@ -1238,22 +1259,26 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
     c->pool.start(nt);
   }
-  uint32_t* d_pk = (uint32_t*)c->packed.p;
-  uint32_t* h_pk = (uint32_t*)c->h_stage;
+  uint8_t* d_pk = (uint8_t*)c->packed.p;
+  uint8_t* h_pk = (uint8_t*)c->h_stage;
   int status = GPC_OK;
   auto pairs_of = [&](int k) { return (k * chunk + chunk <= npairs) ? chunk : npairs - k * chunk; };
-  // the counts of chunk k are on their way: wait for them, then fetch what is valid of every pair (row counts + supports in one copy)
+  int32_t* d_tot = reinterpret_cast<int32_t*>(d_pk + 3 * cb);  // [3][chunk] scratch of k_pair_totals
+  // the counts of chunk k are on their way: wait for them, then fetch the chunk's row counts and records in one copy
   auto download = [&](int k) -> int {
     const int p0 = k * chunk, pc = pairs_of(k);
     HIPCHK(c, hipEventSynchronize(c->e_cnt[k & 3]));
+    memcpy(counts + p0, hc + p0, sizeof(int32_t) * pc);
+    if (ncand) memcpy(ncand + 2 * p0, hn + 2 * p0, sizeof(int32_t) * 2 * pc);
     c->pool.wait_slot(k & 3);  // the expansion of chunk k-4 has left this landing slot
+    size_t recs = 0;
     for (int i = 0; i < pc; ++i) {
       const int cnt = counts[p0 + i];
       if (cnt > cap) status = GPC_E_CAPACITY;
-      const size_t words = hpad + (size_t)(cnt < cap ? cnt : cap);
-      HIPCHK(c, hipMemcpyAsync(h_pk + ((size_t)(k & 3) * chunk + i) * ps, d_pk + ((size_t)(k % 3) * chunk + i) * ps,
-                               sizeof(uint32_t) * words, hipMemcpyDeviceToHost, c->s_out));
+      recs += (size_t)(cnt < cap ? cnt : cap);
     }
+    const size_t bytes = 4 * hpad * chunk + rec * recs;
+    HIPCHK(c, hipMemcpyAsync(h_pk + (size_t)(k & 3) * cb, d_pk + (size_t)(k % 3) * cb, bytes, hipMemcpyDeviceToHost, c->s_out));
     HIPCHK(c, hipEventRecord(c->e_out[k & 3], c->s_out));
     return GPC_OK;
   };
@@ -1261,18 +1286,21 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     const int p0 = k * chunk, pc = pairs_of(k);
     HIPCHK(c, hipEventSynchronize(c->e_out[k & 3]));
     const int parts = c->pool.size() >= 8 ? 4 : 2;
+    const uint8_t* slot = h_pk + (size_t)(k & 3) * cb;
+    const uint8_t* recs = slot + 4 * hpad * chunk;
     for (int i = 0; i < pc; ++i) {
-      const uint32_t* base = h_pk + ((size_t)(k & 3) * chunk + i) * ps;
-      const int32_t* rows = reinterpret_cast<const int32_t*>(base);
+      const int32_t* rows = reinterpret_cast<const int32_t*>(slot) + (size_t)i * hpad;
       const int cnt = counts[p0 + i];
       const long limit = cnt < cap ? cnt : cap;
       long first = 0;
       for (int q = 0; q < parts; ++q) {
         const int y0 = GPC_R + (int)((long)(H - 2 * GPC_R) * q / parts), y1 = GPC_R + (int)((long)(H - 2 * GPC_R) * (q + 1) / parts);
         if (first < limit && y1 > y0)
-          c->pool.push(ExpandJob{base + hpad, rows, H, y0, y1, (int)first, (int)limit, out + (size_t)(p0 + i) * cap, k & 3});
+          c->pool.push(ExpandJob{reinterpret_cast<const uint32_t*>(recs), rows, H, y0, y1, (int)first, (int)limit,
+                                 out + (size_t)(p0 + i) * cap, k & 3});
         for (int y = y0; y < y1; ++y) first += rows[y];
       }
+      recs += rec * (size_t)limit;  // the next pair's records follow directly
     }
     return GPC_OK;
   };
@@ -1286,19 +1314,17 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     HIPCHK(c, hipEventRecord(c->e_in[ev], c->s_in));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_in[ev], 0));
     if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_out[(k - 3) & 3], 0));  // chunk k-3 has left this result slot
-    uint32_t* slot = d_pk + (size_t)(k % 3) * chunk * ps;
+    uint8_t* slot = d_pk + (size_t)(k % 3) * cb;
     CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * pc));
     CHK(run_preprocess(c, d_l, d_r, W, H, pc, 2, s->gradient_threshold));
     CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * pc, false, (uint32_t*)c->codes.p));
-    const PackedOut po = {reinterpret_cast<int32_t*>(slot), (long)ps, (long)ps};
-    CHK(run_match(c, W, H, pc, s, 2, (const uint8_t*)c->grad.p, slot + hpad, cap, (int32_t*)c->counts.p + p0,
+    const PackedOut po = {reinterpret_cast<int32_t*>(slot), 0l, (long)hpad, d_tot + (size_t)(k % 3) * chunk};
+    CHK(run_match(c, W, H, pc, s, 2, (const uint8_t*)c->grad.p, slot + 4 * hpad * chunk, cap, (int32_t*)c->counts.p + p0,
                   (int32_t*)c->ncand.p + 2 * p0, &po));
     HIPCHK(c, hipEventRecord(c->e_comp[ev], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->s_cnt, c->e_comp[ev], 0));
-    HIPCHK(c, hipMemcpyAsync(counts + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
-    if (ncand)
-      HIPCHK(c, hipMemcpyAsync(ncand + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc,
-                               hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipMemcpyAsync(hc + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipMemcpyAsync(hn + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc, hipMemcpyDeviceToHost, c->s_cnt));
     HIPCHK(c, hipEventRecord(c->e_cnt[ev], c->s_cnt));
     if (k >= 1) CHK(download(k - 1));
     if (k >= 2) CHK(expand(k - 2));

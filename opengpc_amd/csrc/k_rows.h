@@ -23,6 +23,13 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
   return s;
 }
 
+// totals[pair] = supports of the pair (sum of its row counts).  grid: (npairs)
+__global__ __launch_bounds__(RM_THREADS) void k_pair_totals(const int32_t* __restrict__ rowcnt, int H,
+                                                           int32_t* __restrict__ totals) {
+  const int s = block_prefix_rows(rowcnt + (long)blockIdx.x * H, GPC_R, H - GPC_R);
+  if (threadIdx.x == 0) totals[blockIdx.x] = s;
+}
+
 // Expands the staged rows into the caller's array, rows in ascending order.
 // mode 0: gpc_support {x, y, float(xL-xR)}; mode 1: gpc_correspondence {xL, y, xR, y};
 // mode 2: PACKED -- the staged words (xL | xR << 16) themselves, made contiguous, plus a copy of the pair's
@@ -38,8 +45,16 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
 __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
     const uint32_t* __restrict__ staged, const int32_t* __restrict__ rowcnt, int W, int H, int mode,
     void* __restrict__ out, int cap, int32_t* __restrict__ counts, const int32_t* __restrict__ img_stats,
-    int32_t* __restrict__ ncand, int rows_per_wg, int32_t* __restrict__ rows_out, long packed_stride, long rows_stride) {
+    int32_t* __restrict__ ncand, int rows_per_wg, int32_t* __restrict__ rows_out, long packed_stride, long rows_stride,
+    const int32_t* __restrict__ totals) {
   const int y0 = GPC_R + blockIdx.x * rows_per_wg, pair = blockIdx.y;
+  // packed mode with `totals`: the pairs' records follow one another without gaps (every pair cut at `cap`), so that
+  // a chunk's results leave in ONE copy; packed_stride is ignored
+  long cbase = -1;
+  if (mode == 2 && totals) {
+    cbase = 0;
+    for (int q = 0; q < pair; ++q) cbase += min(totals[q], cap);
+  }
   const int32_t* rc = rowcnt + (long)pair * H;
   int off = block_prefix_rows(rc, GPC_R, y0);
   const int yend = min(y0 + rows_per_wg, H - GPC_R);
@@ -59,7 +74,7 @@ __global__ __launch_bounds__(RM_THREADS) void k_gather_rows(
         o[pos * 3 + 2] = __float_as_uint((float)(xl - xr));
       }
     } else if (mode == 2) {
-      uint32_t* o = reinterpret_cast<uint32_t*>(out) + pair * packed_stride;  // packed_stride: words between pairs
+      uint32_t* o = reinterpret_cast<uint32_t*>(out) + (cbase >= 0 ? cbase : pair * packed_stride);  // packed_stride: words between pairs
       for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
         const int pos = off + i;
         if (pos >= cap) break;

@@ -211,8 +211,11 @@ def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
     dev = torch.device("cuda", 0)
     ctx = g.Context(0)
     try:
+        # (on the link a support takes three bytes when x and the filtered disparity fit 24 bits, else the 32-bit word:
+        #  2064 px with dispHigh 4000 needs 12 + 13 bits; dispHigh 0 and 1 are the narrowest disparity fields)
         for (W, H, P, fo, disp) in [(1024, 436, 11, "zero", 128), (272, 61, 37, "tau", 128), (528, 41, 5, "tau", 9),
-                                    (2064, 36, 3, "zero", 128), (48, 30, 2, "zero", 128)]:
+                                    (2064, 36, 3, "zero", 128), (48, 30, 2, "zero", 128), (2064, 36, 3, "tau", 4000),
+                                    (1024, 60, 4, "zero", 4000), (272, 61, 3, "zero", 0), (272, 61, 3, "zero", 1)]:
             ctx.load_forest(forest_paths[fo], W, H)
             s = g.Settings(5, disp, 0, True, False, 1)
             Lh, Rh = synth_batch(W, H, [3 * i + 1 for i in range(P)])
@@ -231,7 +234,7 @@ def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
                                           d_cnt2.data_ptr(), d_nc2.data_ptr())
             ctx.synchronize()
             cnt = d_cnt.cpu().numpy()
-            assert np.array_equal(cnt, d_cnt2.cpu().numpy()) and torch.equal(d_nc, d_nc2) and cnt.sum() > 0
+            assert np.array_equal(cnt, d_cnt2.cpu().numpy()) and torch.equal(d_nc, d_nc2) and (cnt.sum() > 0 or disp < 2)
             pk, rows = d_pk.cpu().numpy().view(np.uint32), d_rows.cpu().numpy()
             ref = []
             for i in range(P):

@@ -37,6 +37,25 @@ def main():
     def both():
         h2d()
         d2h()
+    piece = 7 << 20
+
+    def h2d_pieces():
+        with torch.cuda.stream(s1):
+            for o in range(0, nb - piece + 1, piece):
+                d_a[o:o + piece].copy_(h_in[o:o + piece], non_blocking=True)
+
+    def d2h_pieces():
+        with torch.cuda.stream(s2):
+            for o in range(0, nb - piece + 1, piece):
+                h_out[o:o + piece].copy_(d_b[o:o + piece], non_blocking=True)
+
+    def both_pieces():
+        h2d_pieces()
+        d2h_pieces()
+    npc = (nb // piece) * piece
+    res["h2d_7MiB_pieces_GBs"] = round(npc / timed(h2d_pieces) / 1e9, 1)
+    res["d2h_7MiB_pieces_GBs"] = round(npc / timed(d2h_pieces) / 1e9, 1)
+    res["both_ways_7MiB_pieces_each_GBs"] = round(npc / timed(both_pieces) / 1e9, 1)
     res["h2d_GBs"] = round(nb / timed(h2d) / 1e9, 1)
     res["d2h_GBs"] = round(nb / timed(d2h) / 1e9, 1)
     res["both_ways_each_GBs"] = round(nb / timed(both) / 1e9, 1)
