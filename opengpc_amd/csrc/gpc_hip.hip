@@ -1104,6 +1104,17 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   return GPC_OK;
 }
 
+// page-locked landing area for npairs counts + 2*npairs candidate counts
+static int pinned_counts(gpc_hip_ctx* c, int npairs) {
+  if ((size_t)npairs * 3 <= c->h_cnt_cap) return GPC_OK;
+  if (c->h_cnt) HIPCHK(c, hipHostFree(c->h_cnt));
+  c->h_cnt = nullptr;
+  c->h_cnt_cap = 0;
+  HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, sizeof(int32_t) * 3 * (size_t)npairs, hipHostMallocDefault));
+  c->h_cnt_cap = (size_t)npairs * 3;
+  return GPC_OK;
+}
+
 static int batch_streams(gpc_hip_ctx* c) {
   if (c->s_in) return GPC_OK;
   HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
@@ -1138,11 +1149,16 @@ static int match_batch_unpacked(gpc_hip_ctx* c, const uint8_t* rawL, const uint8
   CHK(ensure(c, c->counts, sizeof(int32_t) * npairs));
   CHK(ensure(c, c->ncand, sizeof(int32_t) * 2 * npairs));
   CHK(batch_streams(c));
+  CHK(pinned_counts(c, npairs));  // (a copy straight into the caller's pageable arrays blocks the host, see gpc_hip_match_batch)
+  int32_t* hc = c->h_cnt;
+  int32_t* hn = c->h_cnt + npairs;
   int status = GPC_OK;
   // fetch the supports of chunk k (its counts are on their way: wait for them, then one copy per pair)
   auto collect = [&](int k) -> int {
     const int p0 = k * chunk, pc = (p0 + chunk <= npairs) ? chunk : npairs - p0;
     HIPCHK(c, hipEventSynchronize(c->e_cnt[k & 1]));
+    memcpy(counts + p0, hc + p0, sizeof(int32_t) * pc);
+    if (ncand) memcpy(ncand + 2 * p0, hn + 2 * p0, sizeof(int32_t) * 2 * pc);
     for (int p = p0; p < p0 + pc; ++p) {
       const int ncopy = counts[p] < cap ? counts[p] : cap;
       if (counts[p] > cap) status = GPC_E_CAPACITY;
@@ -1165,10 +1181,8 @@ static int match_batch_unpacked(gpc_hip_ctx* c, const uint8_t* rawL, const uint8
                                    (int32_t*)c->counts.p + p0, (int32_t*)c->ncand.p + 2 * p0));
     HIPCHK(c, hipEventRecord(c->e_comp[slot], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->s_cnt, c->e_comp[slot], 0));
-    HIPCHK(c, hipMemcpyAsync(counts + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
-    if (ncand)
-      HIPCHK(c, hipMemcpyAsync(ncand + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc,
-                               hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipMemcpyAsync(hc + p0, (int32_t*)c->counts.p + p0, sizeof(int32_t) * pc, hipMemcpyDeviceToHost, c->s_cnt));
+    HIPCHK(c, hipMemcpyAsync(hn + 2 * p0, (int32_t*)c->ncand.p + 2 * p0, sizeof(int32_t) * 2 * pc, hipMemcpyDeviceToHost, c->s_cnt));
     HIPCHK(c, hipEventRecord(c->e_cnt[slot], c->s_cnt));
     if (k >= 1) CHK(collect(k - 1));
   }
@@ -1241,13 +1255,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     HIPCHK(c, hipHostMalloc(&c->h_stage, stage_bytes, hipHostMallocDefault));
     c->h_stage_cap = stage_bytes;
   }
-  if ((size_t)npairs * 3 > c->h_cnt_cap) {
-    if (c->h_cnt) HIPCHK(c, hipHostFree(c->h_cnt));
-    c->h_cnt = nullptr;
-    c->h_cnt_cap = 0;
-    HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, sizeof(int32_t) * 3 * (size_t)npairs, hipHostMallocDefault));
-    c->h_cnt_cap = (size_t)npairs * 3;
-  }
+  CHK(pinned_counts(c, npairs));
   int32_t* hc = c->h_cnt;               // counts
   int32_t* hn = c->h_cnt + npairs;      // candidate counts
   CHK(batch_streams(c));
