@@ -23,6 +23,7 @@
 #include "k_global.h"
 #include "k_hash.h"
 #include "k_hashtable.h"
+#include "k_partition.h"
 #include "k_preprocess.h"
 #include "k_rowjoin.h"
 #include "k_rows.h"
@@ -147,6 +148,9 @@ struct gpc_hip_ctx {
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2], hrec;
+  DevBuf gpart;       // partition plan of the non-epipolar matcher (k_partition.h) + one overflow word for the batch
+  int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
+  int no_partition = 0;       // GPC_HIP_NO_PARTITION: always take the radix-sort path (A/B checks)
   DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
@@ -515,7 +519,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
                        (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
                        (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
-                       jp.rshift, rpw);                                                                       \
+                       jp.rshift, rpw, gpc::RjVirt());                                                         \
   } while (0)
 #define LAUNCH_JOIN_W(SPT, NT) do { if (wide) LAUNCH_JOIN(SPT, NT, true); else LAUNCH_JOIN(SPT, NT, false); } while (0)
 #define LAUNCH_JOIN_S(NT)                      \
@@ -611,10 +615,112 @@ int radix_passes(gpc_hip_ctx* c, const GlobalPlan& g, int npairs, uint32_t* keys
 }
 
 // Non-epipolar mode: one device-wide stable radix sort per pair (k_global.h).
+// Non-epipolar matcher by partition + LDS join (k_partition.h).  *done = false when some partition is too large for one
+// workgroup (heavily duplicated codes): nothing has been written then and the caller takes the radix-sort path.
+// The overflow word is read back, so this mode synchronises the stream once per call.
+int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int npairs, const gpc_settings* s, int mode,
+                        const uint8_t* d_cand, void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand, bool* done) {
+  *done = false;
+  const bool wide = wide_codes(c);
+  const int bits = wide ? 32 : code_bits(c);
+  gpc::GpLayout L;
+  int lb = bits < 8 ? bits : 8;  // GP_MAXBINS
+  L.nbins = 1 << lb;
+  L.bshift = bits - lb;
+  L.target = 1400;  // records per side a partition aims at: a third of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
+  L.pmax = g.nmax / L.target + 2;  // cuts happen where a running count <= nmax passes a multiple of the target
+  const int rows = H - 2 * GPC_R;
+  L.rows_per_chunk = rows >= 64 ? 16 : (rows + 3) / 4;  // >= 4 chunks per image, ~1.7 k workgroups at 32 pairs of 436 rows
+  L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
+  L.o_off = 0;
+  L.o_pbin = L.o_off + 2 * (L.pmax + 1);
+  L.o_rowcnt = L.o_pbin + L.pmax + 1;
+  L.o_misc = L.o_rowcnt + L.pmax;
+  L.ps = L.o_misc + 8;
+  const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
+  const size_t plan_bytes = sizeof(int32_t) * ((size_t)L.ps * npairs + 4);
+  CHK(ensure(c, c->gpart, sizeof(int32_t) * tab_ints + plan_bytes));
+  CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)(g.nmax / 2) * npairs));
+  if (!c->h_flag) HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
+  int32_t* tabs = (int32_t*)c->gpart.p;
+  int32_t* part = tabs + tab_ints;
+  int32_t* d_flag = part + (size_t)L.ps * npairs;
+  const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const uint8_t* wcand = wide ? d_cand : nullptr;
+  uint32_t* keys = (uint32_t*)c->gkeys[0].p;
+  uint32_t* vals = (uint32_t*)c->gvals[0].p;
+  dim3 cgrid(L.nchunk, 2, npairs);
+  {
+    Timed t(c, KID_GLOBAL_KEYS);
+    HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
+    hipLaunchKernelGGL(gpc::k_gp_hist, cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
+                       (long)L.nbins * L.nchunk);
+    const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_gp_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)plan_lds));
+    hipLaunchKernelGGL(gpc::k_gp_plan, dim3(npairs), dim3(GP_THREADS), plan_lds, c->stream, (const int32_t*)tabs,
+                       (const int32_t*)c->stats.p, part, L, d_flag);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*c->h_flag) return GPC_OK;  // the caller sorts instead
+  {
+    Timed t(c, KID_GLOBAL_SORT);
+    hipLaunchKernelGGL(gpc::k_gp_scatter, cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                       (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    Timed t(c, KID_GLOBAL_MATCH);
+    gpc::RjVirt v;
+    v.keys = keys;
+    v.vals = vals;
+    v.part = part;
+    v.staged = (uint32_t*)c->staged.p;
+    v.recs = g.bs.recs;
+    v.ps = L.ps;
+    v.o_off = L.o_off;
+    v.o_pbin = L.o_pbin;
+    v.o_rowcnt = L.o_rowcnt;
+    v.o_misc = L.o_misc;
+    v.pmax = L.pmax;
+    v.bshift = L.bshift;
+    v.dw = make_divw(W);
+    v.vtol = s->vertical_tolerance;
+    const int log2s = 13;  // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU
+    const size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
+    const int apply_filter = (mode == 0);
+    const dim3 jgrid(L.pmax, npairs);
+#define LAUNCH_VJOIN(WIDE)                                                                                              \
+  do {                                                                                                                  \
+    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<4, 1024, WIDE, true>);                              \
+    HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((gpc::k_row_join<4, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
+                       (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 0, 1, v);                                          \
+  } while (0)
+    if (wide) LAUNCH_VJOIN(true); else LAUNCH_VJOIN(false);
+#undef LAUNCH_VJOIN
+    hipLaunchKernelGGL(gpc::k_gp_gather, dim3((L.pmax + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
+                       (const uint32_t*)c->staged.p, (const int32_t*)part, L, (const uint32_t*)vals, g.bs.recs, make_divw(W),
+                       mode, d_out, g.bs.out, cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
+    HIPCHK(c, hipGetLastError());
+  }
+  *done = true;
+  return GPC_OK;
+}
+
 int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                      void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
   GlobalPlan g;
   CHK(plan_global(c, W, H, npairs, mode, cap, false, g));
+  if (!c->no_partition) {
+    bool done = false;
+    CHK(run_partition_match(c, g, W, H, npairs, s, mode, d_cand, d_out, cap, d_counts, d_ncand, &done));
+    if (done) return GPC_OK;
+  }
   const int apply_filter = (mode == 0);
   const uint32_t* codes = (const uint32_t*)c->codes.p;
   const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;  // 32-bit codes: 0xFFFFFFFF is told from the sentinel by the candidate byte
@@ -766,6 +872,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (ht && atoi(ht) > 0 && atoi(ht) <= 64) c->hash_tpw = atoi(ht);
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
+  c->no_partition = getenv("GPC_HIP_NO_PARTITION") != nullptr;
   const char* ck = getenv("GPC_HIP_CHUNK");
   if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
@@ -783,7 +890,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed};
+                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed, &c->gpart};
   while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -802,6 +909,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   c->pool.stop();
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+  if (c->h_flag) (void)hipHostFree(c->h_flag);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GPC_OK;

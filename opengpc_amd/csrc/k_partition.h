@@ -1,0 +1,321 @@
+// k_partition.h -- non-epipolar ("global") sort-matcher without a device-wide sort.
+//
+// Replaces, for settings.epipolarMode_ == false and useHashtable_ == false, the two std::sort calls and the
+// merge scan of Forest::findCorrespondences (inference.hpp:227-254) and the filter of Forest::rectifiedMatch
+// (inference.hpp:384-391) -- like k_global.h, which stays as the fallback.
+//
+// A code must be unique over the whole left image and over the whole right image, and the output is ordered by
+// code.  Instead of sorting all records (four 8-bit radix passes over ~570 k records per pair), the records are
+// PARTITIONED into contiguous code ranges of a few hundred to ~1400 records per side, and every partition goes
+// through the same LDS hash join + counting rank as an image row of the epipolar matcher (k_rowjoin.h, VIRT):
+// partitions in ascending order and ranks inside a partition give the reference's output order.
+//   1. k_gp_hist     fine histogram of the top code bits (<= 4096 bins) per chunk of rows, in LDS; k_g_scan over the
+//                    (bin, chunk) table gives every chunk the start of its records in every bin;
+//   2. k_gp_plan     per pair: cuts where the running count max(nL, nR) passes a multiple of the target
+//                    size (so a partition is a run of consecutive bins, adapted to the image's code distribution),
+//                    start positions of every bin and partition, and an OVERFLOW flag when a partition exceeds what
+//                    one workgroup can join (heavily duplicated codes: striped images) -- the host then takes the
+//                    radix-sort path of k_global.h;
+//   3. k_gp_scatter  records (code, pixel index) to their bin's stretch (positions from an LDS copy of the chunk's starts);
+//   4. k_row_join<4, 1024, WIDE, true>  one workgroup per partition;
+//   5. k_gp_gather   matches -> gpc_support / gpc_correspondence in partition order.
+// Order inside a bin's stretch is arbitrary (LDS atomics); nothing depends on it: the join carries
+// positions, and the one place the reference's order among EQUAL codes matters (tail quirk Q2: first of two equal
+// targets in mask order) takes the smaller pixel index explicitly.
+#pragma once
+#include "gpc_device.h"
+#include "k_global.h"
+#include "k_rows.h"
+
+namespace gpc {
+
+#define GP_MAXBINS 256    // bins = 8 top code bits: more destinations make the scatter's runs too short to coalesce (measured per 32 pairs:
+                          // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS)
+#define GP_NB 4096          // records per side a partition may hold: k_row_join<4, 1024>
+#define GP_THREADS 1024
+// tabs: [npairs * 2][nbins * nchunk] int32 -- records per (bin, chunk of rows) of one image, bin-major; after the
+//       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
+// plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][first bin : pmax + 1][rowcnt : pmax][misc : 8]
+// misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
+struct GpLayout {
+  int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
+  long ps;                       // ints per pair in the plan blocks
+  int o_off, o_pbin, o_rowcnt, o_misc;
+};
+#define GP_NPARTS 0
+#define GP_OVERFLOW 1
+#define GP_LASTR 2
+
+// No global atomics anywhere (scattered ones run at ~20 G/s on MI355X: 18 M records took 0.76 ms to count and 1.5 ms to
+// place that way): a workgroup counts the records of its chunk of rows per bin in LDS, the table is scanned, and the
+// scatter hands out positions from an LDS copy of its chunk's starts.
+// grid: (nchunk, 2, npairs)
+__global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
+                                                        const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
+                                                        int32_t* __restrict__ tabs, GpLayout g) {
+  __shared__ int s_cnt[GP_MAXBINS];
+  const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
+  for (int i = threadIdx.x; i < g.nbins; i += GP_THREADS) s_cnt[i] = 0;
+  __syncthreads();
+  const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
+  const long img = pair * codes_stride + (long)side * H * W;
+  for (int y = y0; y < y1; ++y) {
+    const uint32_t* row = codes + img + (long)y * W;
+    const uint8_t* crow = cand ? cand + img + (long)y * W : nullptr;
+    for (int x = threadIdx.x; x < W; x += GP_THREADS) {
+      const uint32_t c = row[x];
+      if (g_is_record(c, crow, x, W)) atomicAdd(&s_cnt[c >> g.bshift], 1);
+    }
+  }
+  __syncthreads();
+  int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
+  for (int i = threadIdx.x; i < g.nbins; i += GP_THREADS) tab[i * g.nchunk + chunk] = s_cnt[i];
+}
+
+// exclusive block scan of one value per thread (1024 threads); returns the exclusive prefix, *total gets the sum
+__device__ __forceinline__ uint32_t gp_block_exscan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(v);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t base = incl - v, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += s_w[w];
+    tot += s_w[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base;
+}
+
+// grid: (npairs); 1024 threads, nbins / 1024 consecutive bins each.  tabs are scanned: entry (b, 0) = start of bin b.
+__global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restrict__ tabs, const int32_t* __restrict__ stats,
+                                                        int32_t* __restrict__ plan, GpLayout g,
+                                                        int32_t* __restrict__ batch_overflow) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_praw[GP_MAXBINS];  // running count max(nL, nR) before the bin, divided by the target
+  __shared__ int32_t s_sl[GP_MAXBINS + 1], s_sr[GP_MAXBINS + 1];  // start of every bin per side (+ the totals)
+  extern __shared__ int32_t s_off[];       // [2][pmax + 1]
+  const int pair = blockIdx.x;
+  int32_t* blk = plan + pair * g.ps;
+  int32_t* misc = blk + g.o_misc;
+  const int32_t* tl_ = tabs + (long)(pair * 2) * g.nbins * g.nchunk;
+  const int32_t* tr_ = tl_ + (long)g.nbins * g.nchunk;
+  const int NL = stats[(pair * 2) * GPC_STAT_STRIDE + GPC_STAT_NCAND], NR = stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < g.nbins; b += GP_THREADS) {
+    s_sl[b] = tl_[(long)b * g.nchunk];
+    s_sr[b] = tr_[(long)b * g.nchunk];
+  }
+  if (tid == 0) {
+    s_sl[g.nbins] = NL;
+    s_sr[g.nbins] = NR;
+  }
+  __syncthreads();
+  constexpr int BPT = GP_MAXBINS >= GP_THREADS ? GP_MAXBINS / GP_THREADS : 1;
+  const int bpt = (g.nbins + GP_THREADS - 1) / GP_THREADS;  // <= BPT
+  uint32_t m[BPT], sm = 0;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int b = tid * bpt + i;
+    const bool in = i < bpt && b < g.nbins;
+    m[i] = in ? (uint32_t)max(s_sl[b + 1] - s_sl[b], s_sr[b + 1] - s_sr[b]) : 0u;
+    sm += m[i];
+  }
+  uint32_t tm;
+  uint32_t am = gp_block_exscan(sm, s_w, &tm);
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int b = tid * bpt + i;
+    if (i < bpt && b < g.nbins) {
+      s_praw[b] = am / (uint32_t)g.target;
+      am += m[i];
+    }
+  }
+  __syncthreads();
+  // a bin starts a partition when its raw number differs from its predecessor's; partition id = cuts before it
+  uint32_t ncut = 0;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int b = tid * bpt + i;
+    if (i < bpt && b < g.nbins) ncut += (b == 0 || s_praw[b] != s_praw[b - 1]) ? 1u : 0u;
+  }
+  uint32_t nparts;
+  uint32_t id = gp_block_exscan(ncut, s_w, &nparts);
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int b = tid * bpt + i;
+    if (i < bpt && b < g.nbins && (b == 0 || s_praw[b] != s_praw[b - 1])) {
+      if ((int)id <= g.pmax) {
+        s_off[id] = s_sl[b];
+        s_off[g.pmax + 1 + id] = s_sr[b];
+        blk[g.o_pbin + id] = b;  // the partition's first bin: its codes start at b << bshift
+      }
+      ++id;
+    }
+  }
+  if (tid == 0 && (int)nparts <= g.pmax) {
+    s_off[nparts] = NL;
+    s_off[g.pmax + 1 + nparts] = NR;
+    blk[g.o_pbin + nparts] = g.nbins;
+  }
+  __syncthreads();
+  const bool too_many = (int)nparts > g.pmax;  // cannot happen while pmax >= records / target + 2; checked anyway
+  int over = too_many ? 1 : 0, last_r = -1;
+  if (!too_many) {
+    for (int p = tid; p <= (int)nparts; p += GP_THREADS) {
+      blk[g.o_off + p] = s_off[p];
+      blk[g.o_off + g.pmax + 1 + p] = s_off[g.pmax + 1 + p];
+      if (p < (int)nparts) {
+        const int nl = s_off[p + 1] - s_off[p], nr = s_off[g.pmax + 1 + p + 1] - s_off[g.pmax + 1 + p];
+        if (nl > GP_NB || nr > GP_NB) over = 1;
+        if (nr > 0) last_r = p;
+      }
+    }
+  }
+  if (__ballot(over) && (tid & 63) == 0) {
+    atomicOr(&misc[GP_OVERFLOW], 1);
+    atomicOr(batch_overflow, 1);  // one word for the whole batch: what the host reads
+  }
+  for (int o = 32; o > 0; o >>= 1) last_r = max(last_r, __shfl_xor(last_r, o));
+  if ((tid & 63) == 0 && last_r >= 0) atomicMax(&misc[GP_LASTR], last_r);
+  if (tid == 0) misc[GP_NPARTS] = too_many ? 0 : (int32_t)nparts;
+}
+
+// grid: (nchunk, 2, npairs); records of side s of a pair live at keys / vals + pair * recs + s * (recs / 2).
+// The chunk's pixels go through in tiles of GP_TILE: the tile's records are first put in bin order in LDS, then
+// written out by consecutive threads, so that every bin's run of a tile leaves as one contiguous piece.
+#define GP_TILE 4096
+__global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
+                                                           const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
+                                                           const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long recs) {
+  __shared__ int s_cur[GP_MAXBINS];      // where the chunk's next record of a bin goes (global position)
+  __shared__ int s_tcnt[GP_MAXBINS];     // records of the tile per bin, then their first place in the tile
+  __shared__ int s_gofs[GP_MAXBINS];     // global position of the tile's first record of a bin minus its place in the tile
+  __shared__ uint32_t s_key[GP_TILE], s_val[GP_TILE];
+  __shared__ uint32_t s_wsum[4];
+  const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
+  if (tid < g.nbins) s_cur[tid] = tab[tid * g.nchunk + chunk];
+  uint32_t* k = keys + pair * recs + side * (recs / 2);
+  uint32_t* v = vals + pair * recs + side * (recs / 2);
+  const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
+  const long img = pair * codes_stride + (long)side * H * W;
+  const uint32_t* im = codes + img;
+  const uint8_t* cm = cand ? cand + img : nullptr;
+  constexpr int PPT = GP_TILE / GP_THREADS;
+  for (int q0 = y0 * W; q0 < y1 * W; q0 += GP_TILE) {
+    if (tid < GP_MAXBINS) s_tcnt[tid] = 0;
+    __syncthreads();
+    uint32_t c[PPT], pix[PPT];
+    int lr[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int q = q0 + i * GP_THREADS + tid;
+      lr[i] = -1;
+      pix[i] = (uint32_t)q;
+      c[i] = 0u;
+      if (q < y1 * W) {
+        c[i] = im[q];
+        const int yy = divw((uint32_t)q, wd), x = q - yy * W;
+        if (g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, x, W)) lr[i] = atomicAdd(&s_tcnt[c[i] >> g.bshift], 1);
+      }
+    }
+    __syncthreads();
+    int ntile = 0;
+    if (tid < GP_MAXBINS) {  // 256 bins: four waves scan, the first ones' sums carry over
+      const uint32_t cnt = (uint32_t)s_tcnt[tid];
+      const uint32_t incl = wave_incl_scan(cnt);
+      if (lane == 63) s_wsum[wave] = incl;
+      s_tcnt[tid] = (int)(incl - cnt);  // exclusive within the wave for now
+    }
+    __syncthreads();
+    if (tid < GP_MAXBINS) {
+      int base = 0;
+      for (int w = 0; w < wave; ++w) base += (int)s_wsum[w];
+      s_tcnt[tid] += base;  // first place of the bin in the tile
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+      if (lr[i] >= 0) {
+        const int place = s_tcnt[c[i] >> g.bshift] + lr[i];
+        s_key[place] = c[i];
+        s_val[place] = pix[i];
+      }
+    ntile = (int)(s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]);
+    if (tid < g.nbins) s_gofs[tid] = s_cur[tid] - s_tcnt[tid];
+    __syncthreads();
+    if (tid < g.nbins) {  // advance the chunk's cursors by what this tile holds of the bin
+      const int nxt = (tid + 1 < GP_MAXBINS) ? s_tcnt[tid + 1] : ntile;
+      s_cur[tid] += nxt - s_tcnt[tid];
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int j = i * GP_THREADS + tid;
+      if (j < ntile) {
+        const uint32_t kk = s_key[j];
+        const int pos = s_gofs[kk >> g.bshift] + j;
+        k[pos] = kk;
+        v[pos] = s_val[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Matches of the partitions (staged by the join as positions xvL | xvR << 16 inside the partition) -> the caller's
+// array in partition order.  grid: (ceil(pmax / GPG_PARTS), npairs)
+#define GPG_PARTS 2
+__global__ __launch_bounds__(RM_THREADS) void k_gp_gather(const uint32_t* __restrict__ staged, const int32_t* __restrict__ part,
+                                                          GpLayout g, const uint32_t* __restrict__ vals, long recs, GpcDivW wd,
+                                                          int mode, void* __restrict__ out, long out_stride_bytes, int cap,
+                                                          int32_t* __restrict__ counts, const int32_t* __restrict__ stats,
+                                                          int32_t* __restrict__ ncand) {
+  const int pair = blockIdx.y;
+  const int32_t* blk = part + pair * g.ps;
+  const int nparts = blk[g.o_misc + GP_NPARTS];
+  const int p0 = blockIdx.x * GPG_PARTS;
+  const bool last_wg = blockIdx.x == gridDim.x - 1;
+  if (p0 >= nparts && !last_wg) return;
+  const int32_t* rc = blk + g.o_rowcnt;
+  int off = block_prefix_rows(rc, 0, min(p0, nparts));
+  const int pend = min(p0 + GPG_PARTS, nparts);
+  const uint32_t* vl = vals + pair * recs;
+  const uint32_t* vr = vl + recs / 2;
+  const uint32_t* st = staged + pair * (recs / 2);
+  char* o = reinterpret_cast<char*>(out) + pair * out_stride_bytes;
+  for (int p = p0; p < pend; ++p) {
+    const int cnt = rc[p], ol = blk[g.o_off + p], orr = blk[g.o_off + g.pmax + 1 + p];
+    for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
+      const int pos = off + i;
+      if (pos >= cap) break;
+      const uint32_t v = st[ol + i];
+      const uint32_t kl = vl[ol + (v & 0xFFFFu)], kr = vr[orr + (v >> 16)];
+      const int yl = divw(kl, wd), yr = divw(kr, wd);
+      const int xl = (int)kl - yl * wd.W, xr = (int)kr - yr * wd.W;
+      if (mode == 0) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(o) + (long)pos * 3;
+        q[0] = xl;
+        q[1] = yl;
+        q[2] = __float_as_uint((float)(xl - xr));
+      } else {
+        reinterpret_cast<int4*>(o)[pos] = make_int4(xl, yl, xr, yr);
+      }
+    }
+    off += cnt;
+  }
+  if (last_wg && threadIdx.x == 0) {
+    int total = off;
+    for (int p = pend; p < nparts; ++p) total += rc[p];  // (pend == nparts for the last workgroup: nothing to add)
+    counts[pair] = total;
+    if (ncand) {
+      ncand[2 * pair + 0] = stats[(pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+      ncand[2 * pair + 1] = stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+    }
+  }
+}
+
+}  // namespace gpc

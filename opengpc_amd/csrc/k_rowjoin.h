@@ -150,6 +150,20 @@ struct RjOcc {
   static constexpr int kWaves = (SPT >= 8) ? 4 : 8;
 };
 
+// VIRT (k_partition.h): the "rows" are partitions of the non-epipolar matcher -- dense record arrays (code, pixel
+// index) of a contiguous code range per side instead of two image rows; a record's "x" is its position in the
+// partition, the disparity filter looks the pixel indices up, and results go to the partition's stretch of v.staged.
+struct RjVirt {
+  const uint32_t* keys;   // [npairs][recs]: side s of a pair at + s * (recs / 2)
+  const uint32_t* vals;   // pixel index y * W + x of the record
+  int32_t* part;          // per pair (stride ps ints): cursors, partition offsets, match counts, misc (GpLayout)
+  uint32_t* staged;       // [npairs][recs / 2]  (xvL | xvR << 16) of a partition's matches at its left offset
+  long recs, ps;
+  int o_off, o_pbin, o_rowcnt, o_misc, pmax, bshift;
+  GpcDivW dw;
+  int vtol;
+};
+
 // codes:   [npairs*2][H][W]   (image 2p = left, 2p+1 = right)
 // cand:    [npairs*2][H][W]   candidate bytes (grad, or the caller's scattered mask): WIDE only
 // staged:  [npairs][H][W]     packed (xL | xR<<16), first rowcnt entries of each row valid
@@ -161,11 +175,11 @@ struct RjOcc {
 // dynamic LDS: 8*(S+1) bytes  (16 KiB for W = 1024: 8 workgroups per CU = 32 waves, 64 VGPRs)
 // Wide rows use more threads per row before more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
-template <int SPT, int NT, bool WIDE>
+template <int SPT, int NT, bool WIDE, bool VIRT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, NT>::kWaves, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, const uint8_t* __restrict__ cand, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
-    int log2s, int rshift, int rpw) {
+    int log2s, int rshift, int rpw, RjVirt v) {
   constexpr int NB = NT * SPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
   __shared__ uint32_t s_max_key;
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   __shared__ int s_sp_l, s_sp_r;   // WIDE: left / right candidates of this row whose code is 0xFFFFFFFF
   __shared__ unsigned s_sp_minx;   //       smallest x among the right ones
   __shared__ uint32_t s_w[NT / 64];
+  __shared__ unsigned s_tail_xv, s_sp_xv;  // VIRT: position of the tail / key-less right record with the smallest pixel index
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
   uint32_t* t_w = rj_lds + (S + 1);       // [S]   per slot: seen / duplicate flags of either side (RJ_*), x of a right record in the low half
@@ -185,18 +200,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   const int pair = blockIdx.y;
   const int hshift = 32 - log2s;
   const uint32_t smask = (uint32_t)S - 1u;
-  const int last_r = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
+  // VIRT: this workgroup's partition
+  int32_t* vblk = nullptr;
+  const uint32_t *vkl = nullptr, *vkr = nullptr, *vvl = nullptr, *vvr = nullptr;
+  int v_nl = 0, v_nr = 0, v_offl = 0, v_rshift = 0;
+  uint32_t v_base = 0u;  // first code of the partition: the rank buckets count from there (all its codes share the bits above)
+  if (VIRT) {
+    vblk = v.part + pair * v.ps;
+    const int p = blockIdx.x;
+    if (p >= vblk[v.o_misc + 0]) return;  // GP_NPARTS
+    v_offl = vblk[v.o_off + p];
+    const int offr = vblk[v.o_off + v.pmax + 1 + p];
+    v_nl = vblk[v.o_off + p + 1] - v_offl;
+    v_nr = vblk[v.o_off + v.pmax + 1 + p + 1] - offr;
+    if (v_nl > NB || v_nr > NB) return;  // k_gp_plan has raised the overflow flag: the host takes the radix path
+    vkl = v.keys + pair * v.recs + v_offl;
+    vkr = v.keys + pair * v.recs + v.recs / 2 + offr;
+    vvl = v.vals + pair * v.recs + v_offl;
+    vvr = v.vals + pair * v.recs + v.recs / 2 + offr;
+    const int b0 = vblk[v.o_pbin + p], nb = vblk[v.o_pbin + p + 1] - b0;
+    v_base = (uint32_t)b0 << v.bshift;
+    int lg = v.bshift;  // the partition's codes span nb << bshift <= 2^lg values
+    while ((1 << (lg - v.bshift)) < nb) ++lg;
+    int lnb = 0;
+    while ((1 << lnb) < NB) ++lnb;
+    v_rshift = lg > lnb ? lg - lnb : 0;
+  }
+  const int last_r = VIRT ? vblk[v.o_misc + 2] /* GP_LASTR */ : img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
 
   // A workgroup handles `rpw` consecutive rows; the NEXT row's codes are fetched into registers
   // while the current row is joined, so only the first row's load latency is exposed.
-  const int row0 = GPC_R + blockIdx.x * rpw;
+  const int row0 = VIRT ? (int)blockIdx.x : GPC_R + blockIdx.x * rpw;
   uint32_t ncl[SPT], ncr[SPT];
   uint32_t nspl = 0u, nspr = 0u;  // WIDE: bit j = pixel slot j is a candidate whose code is 0xFFFFFFFF
   auto fetch_row = [&](int yy) {
+    nspl = nspr = 0u;
+    if (VIRT) {
+#pragma unroll
+      for (int j = 0; j < SPT; ++j) {
+        const int x = j * NT + tid;
+        ncl[j] = (x < v_nl) ? vkl[x] : RJ_EMPTY;
+        ncr[j] = (x < v_nr) ? vkr[x] : RJ_EMPTY;
+        if (WIDE) {  // every record is a candidate: 0xFFFFFFFF is the key-less code
+          if (x < v_nl && ncl[j] == RJ_EMPTY) nspl |= 1u << j;
+          if (x < v_nr && ncr[j] == RJ_EMPTY) nspr |= 1u << j;
+        }
+      }
+      return;
+    }
     const long ro = ((long)(pair * 2) * H + yy) * W;
     const uint32_t* rl = codes + ro;
     const uint32_t* rr_ = rl + (long)H * W;
-    nspl = nspr = 0u;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const int x = j * NT + tid;
@@ -212,7 +266,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   };
   fetch_row(row0);
 #pragma unroll 1
-  for (int ri = 0; ri < rpw && row0 + ri < H - GPC_R; ++ri) {
+  for (int ri = 0; ri < rpw && (VIRT ? ri == 0 : row0 + ri < H - GPC_R); ++ri) {
   const int y = row0 + ri;
   RJ_STAMP_INIT();
   // ---- 0. this row's codes (already in flight), table clear, next row's loads
@@ -229,7 +283,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       spl = nspl;
       spr = nspr;
     }
-    if (ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
+    if (!VIRT && ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
       // the zeros are made HERE: as a plain constant the compiler keeps them in four registers across the whole row
@@ -283,12 +337,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       if (spl) atomicAdd(&s_sp_l, __popc(spl));
       if (spr) {
         atomicAdd(&s_sp_r, __popc(spr));
-        atomicMin(&s_sp_minx, (unsigned)((__ffs((int)spr) - 1) * NT + tid));
+        if (VIRT) {  // positions carry no order here: the smallest PIXEL INDEX is the first in mask order
+#pragma unroll
+          for (int j = 0; j < SPT; ++j)
+            if ((spr >> j) & 1u) atomicMin(&s_sp_minx, vvr[j * NT + tid]);
+        } else {
+          atomicMin(&s_sp_minx, (unsigned)((__ffs((int)spr) - 1) * NT + tid));
+        }
       }
     }
   }
   __syncthreads();
   RJ_STAMP(1);
+  if (WIDE && VIRT && spr) {  // which position holds the key-less right record with the smallest pixel index (read after the next barrier)
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      if (((spr >> j) & 1u) && vvr[j * NT + tid] == s_sp_minx) s_sp_xv = (unsigned)(j * NT + tid);
+  }
 
   // ---- 2. every record finds its code's slot (read-only) and marks it.  The marks of a side go out
   //      together (one LDS round trip for SPT returning atomics): a record without a slot ORs 0 into
@@ -339,8 +404,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     for (int j = 0; j < SPT; ++j)
       if (kr[j] && kr[j] == tail_key) {
         atomicAdd(&s_tail_cnt, 1);
-        atomicMin(&s_tail_minx, (unsigned)(j * NT + tid));
+        atomicMin(&s_tail_minx, VIRT ? vvr[j * NT + tid] : (unsigned)(j * NT + tid));
       }
+    if (VIRT) {  // positions carry no order: find where the tail record with the smallest pixel index sits
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SPT; ++j)
+        if (kr[j] && kr[j] == tail_key && vvr[j * NT + tid] == s_tail_minx) s_tail_xv = (unsigned)(j * NT + tid);
+    }
   }
   __syncthreads();
   RJ_STAMP(2);
@@ -357,12 +428,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       const uint32_t w = t_w[hl[j]];
       const bool tail = tail_row && kl[j] == tail_key;
       good = !(w & RJ_LDUP) && (tail ? (s_tail_cnt == 2) : ((w & (RJ_RSEEN | RJ_RDUP)) == RJ_RSEEN));
-      xr[j] = tail ? s_tail_minx : (w & 0xFFFFu);
+      xr[j] = tail ? (VIRT ? s_tail_xv : s_tail_minx) : (w & 0xFFFFu);
     } else if (WIDE && ((spl >> j) & 1u)) {
       good = (s_sp_l == 1) && (s_sp_r == (tail_sp ? 2 : 1));
-      xr[j] = s_sp_minx;
+      xr[j] = VIRT ? s_sp_xv : s_sp_minx;
     }
-    if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
+    if (good && apply_filter) {
+      if (VIRT) {  // rectifiedMatch's filter on the two pixels (inference.hpp:384-391)
+        const uint32_t pl = vvl[j * NT + tid], pr = vvr[xr[j]];
+        const int yl = divw(pl, v.dw), yr = divw(pr, v.dw);
+        good = abs(yl - yr) <= v.vtol && abs(((int)pl - yl * v.dw.W) - ((int)pr - yr * v.dw.W)) <= disp_high;
+      } else {
+        good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
+      }
+    }
     if (good) okm |= 1u << j;
   }
   __syncthreads();  // the flag words are dead from here on: their LDS is reused
@@ -376,7 +455,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
-    rb[j] = cl[j] >> rshift;
+    rb[j] = VIRT ? (cl[j] - v_base) >> v_rshift : cl[j] >> rshift;
     rs[j] = 0u;
     if ((okm >> j) & 1u) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
   }
@@ -389,7 +468,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   __syncthreads();
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
-  uint32_t* dst = staged + rowbase * W;
+  uint32_t* dst = VIRT ? v.staged + pair * (v.recs / 2) + v_offl : staged + rowbase * W;
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) {
@@ -398,7 +477,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cl[j]);
       dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
     }
-  if (tid == 0) rowcnt[rowbase] = (int32_t)r_cnt[NB];
+  if (tid == 0) {
+    if (VIRT) vblk[v.o_rowcnt + y] = (int32_t)r_cnt[NB];
+    else rowcnt[rowbase] = (int32_t)r_cnt[NB];
+  }
 #ifdef GPC_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
