@@ -270,3 +270,48 @@ def test_packed_results_are_refused_outside_the_epipolar_sort_matcher(ctx, fores
             ctx.match_batch_device_packed(z.data_ptr(), z.data_ptr(), W, H, 1, s, buf.data_ptr(), 4096, buf.data_ptr(),
                                           buf.data_ptr(), 0)
         assert e.value.status == g.capi.E_UNSUPPORTED
+
+
+def test_partitioned_and_radix_sort_matchers_agree(oracle, forest_paths):
+    """The non-epipolar sort-matcher has two implementations: partition into code ranges + LDS join (k_partition.h)
+    and, as the fallback when a partition is over-full, the device-wide radix sort (k_global.h).
+    GPC_HIP_NO_PARTITION forces the second.  Both against the oracle: a textured pair (partitions fit), a batch, and
+    striped images whose few codes put thousands of records into one partition (the fallback is taken by itself)."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    os.environ["GPC_HIP_NO_PARTITION"] = "1"
+    try:
+        radix = g.Context(0)
+    finally:
+        del os.environ["GPC_HIP_NO_PARTITION"]
+    part = g.Context(0)
+    try:
+        cases = []
+        for (W, H, s_, D, fo) in [(1024, 436, 3, 21, "zero"), (272, 61, 4, 9, "tau"), (2064, 40, 1, 30, "zero")]:
+            cases.append((fo,) + synth_pair(W, H, s_, D))
+        stripes = np.tile((np.arange(1024) // 3 * 37 % 256).astype(np.uint8), (200, 1))
+        cases.append(("zero", stripes, np.roll(stripes, 7, axis=1)))
+        for fo, L, R in cases:
+            H, W = L.shape
+            rc, f = oracle.read_forest(forest_paths[fo], W, H)
+            for ctx in (part, radix):
+                ctx.load_forest(forest_paths[fo], W, H)
+            for disp, vtol in ((128, 1), (6, 0)):
+                want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, disp, vtol, False))
+                for ctx in (part, radix):
+                    got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, disp, vtol, False, False, 1))
+                    assert st == 0 and (nl, nr) == ncand and n == len(want)
+                    assert np.array_equal(got, want.astype(got.dtype))
+        # a batch through both
+        Ls, Rs = zip(*[synth_pair(528, 90, 20 + i, 4 + 2 * i) for i in range(5)])
+        for ctx in (part, radix):
+            ctx.load_forest(forest_paths["tau"], 528, 90)
+        sset = g.Settings(5, 128, 1, False, False, 1)
+        a = part.match_batch(np.stack(Ls), np.stack(Rs), sset, 40000)
+        b = radix.match_batch(np.stack(Ls), np.stack(Rs), sset, 40000)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[1].sum() > 0
+        for i in range(5):
+            assert np.array_equal(a[0][i, : a[1][i]], b[0][i, : b[1][i]])
+    finally:
+        part.close()
+        radix.close()
