@@ -12,6 +12,7 @@
 #define GPC_STAT_STRIDE 4
 #define GPC_STAT_NCAND 0
 #define GPC_STAT_LASTROW 1
+#define GPC_STAT_CODEOR 2  // OR of every code k_hash computed for the image: how many low bits its codes really use
 
 // hash kernel tile: 256 x HT_Y outputs (4 pixels per lane, 4 rows per wave), smooth staged with a 16-byte aligned 16-pixel apron
 #define HT_X 256
@@ -76,6 +77,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);  // row_bcast31 -> rows 2,3
   return v;
+}
+
+// Maximum over the 64 lanes of a wave with the same DPP steps (zeros shift in: the identity of an unsigned maximum);
+// every lane gets the result.  Minimum: ~wave_max_u32(~v).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));  // row_shr:1
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));  // row_shr:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));  // row_shr:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));  // row_shr:8
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));  // row_bcast15 -> rows 1,3
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));  // row_bcast31 -> rows 2,3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Exclusive scan of arr[0 .. NT*SPT) in place by an NT-thread workgroup (thread t owns SPT

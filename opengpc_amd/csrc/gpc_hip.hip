@@ -446,8 +446,8 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   return GPC_OK;
 }
 
-// Significant bits of the codes the current forest can produce: the join buckets its matches on the
-// TOP ones of these (k_rowjoin.h, step 4).  SSE placement (filter.hpp:574-595): test t -> bit t for
+// Significant bits of the codes the current forest can produce (the partitioned matcher bins on the top ones of
+// these, k_partition.h).  SSE placement (filter.hpp:574-595): test t -> bit t for
 // t <= 7, test 8 is OR-ed into bit 0, test t -> bit t-1 for t >= 9; Naive (filter.hpp:245-249): T bits.
 int code_bits(const gpc_hip_ctx* c) {
   const int T = c->forest.num_tests;
@@ -460,7 +460,7 @@ bool wide_codes(const gpc_hip_ctx* c) { return c->naive && c->forest.num_tests =
 
 // How the join kernel covers a row of W pixels: NT threads x SPT pixel slots, table of 1 << log2s slots.
 struct JoinPlan {
-  int nt, spt, log2s, rshift;
+  int nt, spt, log2s;
   size_t lds;
 };
 
@@ -482,10 +482,6 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
   p.log2s = 1;
   while ((1 << p.log2s) < p.nt * p.spt || ((1 << p.log2s) < 2 * (W - 2 * GPC_R) && p.log2s < 14)) ++p.log2s;
   p.lds = ((size_t)8 * ((1u << p.log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
-  int log2nb = 0;
-  while ((1 << log2nb) < p.nt * p.spt) ++log2nb;
-  const int bits = wide_codes(c) ? 32 : code_bits(c);
-  p.rshift = bits > log2nb ? bits - log2nb : 0;
   return p;
 }
 
@@ -519,7 +515,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
                        (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
                        (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
-                       jp.rshift, rpw, gpc::RjVirt());                                                         \
+                       rpw, gpc::RjVirt());                                                                   \
   } while (0)
 #define LAUNCH_JOIN_W(SPT, NT) do { if (wide) LAUNCH_JOIN(SPT, NT, true); else LAUNCH_JOIN(SPT, NT, false); } while (0)
 #define LAUNCH_JOIN_S(NT)                      \
@@ -633,8 +629,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   L.rows_per_chunk = rows >= 64 ? 16 : (rows + 3) / 4;  // >= 4 chunks per image, ~1.7 k workgroups at 32 pairs of 436 rows
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
   L.o_off = 0;
-  L.o_pbin = L.o_off + 2 * (L.pmax + 1);
-  L.o_rowcnt = L.o_pbin + L.pmax + 1;
+  L.o_rowcnt = L.o_off + 2 * (L.pmax + 1);
   L.o_misc = L.o_rowcnt + L.pmax;
   L.ps = L.o_misc + 8;
   const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
@@ -682,11 +677,9 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     v.recs = g.bs.recs;
     v.ps = L.ps;
     v.o_off = L.o_off;
-    v.o_pbin = L.o_pbin;
     v.o_rowcnt = L.o_rowcnt;
     v.o_misc = L.o_misc;
     v.pmax = L.pmax;
-    v.bshift = L.bshift;
     v.dw = make_divw(W);
     v.vtol = s->vertical_tolerance;
     const int log2s = 13;  // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU
@@ -699,7 +692,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
     hipLaunchKernelGGL((gpc::k_row_join<4, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
-                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 0, 1, v);                                          \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v);                                             \
   } while (0)
     if (wide) LAUNCH_VJOIN(true); else LAUNCH_VJOIN(false);
 #undef LAUNCH_VJOIN
@@ -1154,7 +1147,7 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
   HIPCHK(c, hipMemcpyAsync(d_gr, gradL, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_gr + n, gradR, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(d_cm, 0, 2 * n, c->stream));
-  const int32_t init_stats[2 * GPC_STAT_STRIDE] = {0, -1, 0, 0, 0, -1, 0, 0};
+  const int32_t init_stats[2 * GPC_STAT_STRIDE] = {0, -1, 0, 0, 0, -1, 0, 0};  // NCAND, LASTROW, CODEOR, -
   HIPCHK(c, hipMemcpyAsync(c->stats.p, init_stats, sizeof init_stats, hipMemcpyHostToDevice, c->stream));
   const int32_t* masks[2] = {maskL, maskR};
   const int counts[2] = {nL, nR};

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
                                               int tpw) {
   constexpr int RPW = HT_Y / (HT_THREADS / 64);
   __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
-  __shared__ int s_cnt, s_last;
+  __shared__ int s_cnt, s_last, s_or;
 
   // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2) in launch
   // order, so launch-order neighbours never share an L2.  Remapped, XCD k works through its own
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   const int wave = tid >> 6, lane = tid & 63;
   const int x0 = tx0 + 4 * lane;
 
-  if (tid == 0) { s_cnt = 0; s_last = -1; }
+  if (tid == 0) { s_cnt = 0; s_last = -1; s_or = 0; }
 
   // bit 7 of byte j: pixel x0 + j lies inside the image and the 13-pixel margin (constant per lane)
   uint32_t xmask = 0u;
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
   HT_STAMP_INIT();
   fetch(GPC_R + tile0 * HT_Y);
   int cnt = 0, last = -1;
+  uint32_t cor = 0u;  // OR of the codes computed here (candidates or not: a superset costs the join nothing)
   const int T = fp->num_tests;
   int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
   // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t c = rowdo[r] ? code[r][j] : 0u;
+        cor |= c;
         const bool is_cand = (cand8[r] >> (8 * j + 7)) & 1u;
         op[j] = DENSE ? ((NAIVE && !is_cand) ? 0u : c) : (is_cand ? c : GPC_NOCAND);
       }
@@ -448,12 +450,14 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__
     for (int o = 32; o > 0; o >>= 1) {
       cnt += __shfl_xor(cnt, o);
       last = max(last, __shfl_xor(last, o));
+      cor |= (uint32_t)__shfl_xor((int)cor, o);
     }
-    if (lane == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicMax(&s_last, last); }
+    if (lane == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicMax(&s_last, last); atomicOr(&s_or, (int)cor); }
     __syncthreads();
     if (tid == 0 && s_cnt) {
       atomicAdd(&img_stats[img * GPC_STAT_STRIDE + GPC_STAT_NCAND], s_cnt);
       atomicMax(&img_stats[img * GPC_STAT_STRIDE + GPC_STAT_LASTROW], s_last);
+      atomicOr(&img_stats[img * GPC_STAT_STRIDE + GPC_STAT_CODEOR], s_or);
     }
   }
 }

@@ -35,12 +35,12 @@ namespace gpc {
 #define GP_THREADS 1024
 // tabs: [npairs * 2][nbins * nchunk] int32 -- records per (bin, chunk of rows) of one image, bin-major; after the
 //       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
-// plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][first bin : pmax + 1][rowcnt : pmax][misc : 8]
+// plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][rowcnt : pmax][misc : 8]
 // misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
   long ps;                       // ints per pair in the plan blocks
-  int o_off, o_pbin, o_rowcnt, o_misc;
+  int o_off, o_rowcnt, o_misc;
 };
 #define GP_NPARTS 0
 #define GP_OVERFLOW 1
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
       if ((int)id <= g.pmax) {
         s_off[id] = s_sl[b];
         s_off[g.pmax + 1 + id] = s_sr[b];
-        blk[g.o_pbin + id] = b;  // the partition's first bin: its codes start at b << bshift
       }
       ++id;
     }
@@ -157,7 +156,6 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
   if (tid == 0 && (int)nparts <= g.pmax) {
     s_off[nparts] = NL;
     s_off[g.pmax + 1 + nparts] = NR;
-    blk[g.o_pbin + nparts] = g.nbins;
   }
   __syncthreads();
   const bool too_many = (int)nparts > g.pmax;  // cannot happen while pmax >= records / target + 2; checked anyway

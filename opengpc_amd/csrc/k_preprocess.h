@@ -111,6 +111,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   if (bx == 0 && by == 0 && threadIdx.x == 0) {
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_NCAND] = 0;
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_LASTROW] = -1;
+    img_stats[img * GPC_STAT_STRIDE + GPC_STAT_CODEOR] = 0;
   }
 
   const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;

@@ -20,8 +20,8 @@
 //   3. every left record reads its slot: match iff neither side is DUP and the right side was
 //      SEEN (+ disparity filter);
 //   4. output position = rank of the code among the row's matches, by COUNTING on the top
-//      SIGNIFICANT bits of the code (the host passes the shift: a 30-test forest has 29-bit
-//      codes): one returning ds_add per match, an exclusive scan over the NT*SPT bucket counters
+//      bits the image's codes really use (k_hash ORs them into img_stats: bits a forest leaves
+//      clear cost no resolution): one returning ds_add per match, an exclusive scan over the NT*SPT bucket counters
 //      (DPP wave scan), and a look at the < 1 other matches sharing the bucket.
 //      The thread still holds xL and xR, so it writes the packed support straight to its place.
 //
@@ -159,7 +159,7 @@ struct RjVirt {
   int32_t* part;          // per pair (stride ps ints): cursors, partition offsets, match counts, misc (GpLayout)
   uint32_t* staged;       // [npairs][recs / 2]  (xvL | xvR << 16) of a partition's matches at its left offset
   long recs, ps;
-  int o_off, o_pbin, o_rowcnt, o_misc, pmax, bshift;
+  int o_off, o_rowcnt, o_misc, pmax;
   GpcDivW dw;
   int vtol;
 };
@@ -171,7 +171,6 @@ struct RjVirt {
 // grid: (ceil((H - 26) / rpw), npairs); NT threads, NB = NT*SPT >= W; table of S = 1 << log2s slots,
 //       S >= NB, S >= 2*(W-26) where the LDS allows it (only left codes are inserted: load factor
 //       <= 0.5; rows beyond 8218 px fill a 16384-slot table up to W-26 / 16384 < 1)
-// rshift: code >> rshift < NB for every code the forest can produce (host: code bits - log2 NB)
 // dynamic LDS: 8*(S+1) bytes  (16 KiB for W = 1024: 8 workgroups per CU = 32 waves, 64 VGPRs)
 // Wide rows use more threads per row before more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
@@ -179,7 +178,7 @@ template <int SPT, int NT, bool WIDE, bool VIRT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, NT>::kWaves, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, const uint8_t* __restrict__ cand, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
-    int log2s, int rshift, int rpw, RjVirt v) {
+    int log2s, int rpw, RjVirt v) {
   constexpr int NB = NT * SPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
   __shared__ uint32_t s_max_key;
@@ -188,6 +187,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   __shared__ int s_sp_l, s_sp_r;   // WIDE: left / right candidates of this row whose code is 0xFFFFFFFF
   __shared__ unsigned s_sp_minx;   //       smallest x among the right ones
   __shared__ uint32_t s_w[NT / 64];
+  __shared__ uint32_t s_cmin, s_cmax;      // smallest / largest matched code of the row: the rank buckets span that range
   __shared__ unsigned s_tail_xv, s_sp_xv;  // VIRT: position of the tail / key-less right record with the smallest pixel index
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
@@ -203,8 +203,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   // VIRT: this workgroup's partition
   int32_t* vblk = nullptr;
   const uint32_t *vkl = nullptr, *vkr = nullptr, *vvl = nullptr, *vvr = nullptr;
-  int v_nl = 0, v_nr = 0, v_offl = 0, v_rshift = 0;
-  uint32_t v_base = 0u;  // first code of the partition: the rank buckets count from there (all its codes share the bits above)
+  int v_nl = 0, v_nr = 0, v_offl = 0;
   if (VIRT) {
     vblk = v.part + pair * v.ps;
     const int p = blockIdx.x;
@@ -218,13 +217,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     vkr = v.keys + pair * v.recs + v.recs / 2 + offr;
     vvl = v.vals + pair * v.recs + v_offl;
     vvr = v.vals + pair * v.recs + v.recs / 2 + offr;
-    const int b0 = vblk[v.o_pbin + p], nb = vblk[v.o_pbin + p + 1] - b0;
-    v_base = (uint32_t)b0 << v.bshift;
-    int lg = v.bshift;  // the partition's codes span nb << bshift <= 2^lg values
-    while ((1 << (lg - v.bshift)) < nb) ++lg;
-    int lnb = 0;
-    while ((1 << lnb) < NB) ++lnb;
-    v_rshift = lg > lnb ? lg - lnb : 0;
   }
   const int last_r = VIRT ? vblk[v.o_misc + 2] /* GP_LASTR */ : img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
 
@@ -294,6 +286,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       for (int i = tid; i < (8 * (S + 1) + 15) / 16; i += NT) z[i] = zero;
     }
     if (tid == 0) {
+      s_cmin = 0xFFFFFFFFu;
+      s_cmax = 0u;
       s_max_key = 0u;
       s_tail_cnt = 0;
       s_tail_minx = 0xFFFFFFFFu;
@@ -444,6 +438,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     }
     if (good) okm |= 1u << j;
   }
+  if (VIRT) {  // range of the partition's matched codes (one pair of LDS atomics per wave that has a match)
+    uint32_t cmax = 0u, cmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      if ((okm >> j) & 1u) {
+        cmax = max(cmax, cl[j]);
+        cmin = min(cmin, cl[j]);
+      }
+    if (__ballot(okm != 0u)) {  // wave-uniform
+      cmax = wave_max_u32(cmax);
+      cmin = ~wave_max_u32(~cmin);
+      if (lane == 0) {
+        atomicMax(&s_cmax, cmax);
+        atomicMin(&s_cmin, cmin);
+      }
+    }
+  }
   __syncthreads();  // the flag words are dead from here on: their LDS is reused
   RJ_STAMP(3);
 
@@ -452,10 +463,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   //   * matches alone in their bucket written straight from the scan, only shared buckets walked: 553 us;
   //   * matches first appended to a dense list (a wave reserving its stretch with one atomic) and ranked from
   //     there, one match per thread, with 16-bit counters beside the table: 522 us.
+  // The NB buckets divide the range the codes really span, so that bits the forest leaves constant cost no resolution:
+  // rows: [0, 2^bits) with bits from the OR of every code k_hash computed for the left image (a scalar load; tests
+  // that never hold leave their bit clear there); partitions (VIRT): [smallest, largest matched code] of this
+  // partition, reduced above (all its codes share a prefix).  The reduction costs a row kernel 18 us per 256 pairs.
+  uint32_t cbase = 0u;
+  int csh = 0;
+  {
+    uint32_t span;
+    if (VIRT) {
+      cbase = s_cmin;
+      span = s_cmax >= cbase ? s_cmax - cbase : 0u;
+    } else {
+      span = (uint32_t)img_stats[(pair * 2) * GPC_STAT_STRIDE + GPC_STAT_CODEOR];
+    }
+    int lnb = 0;
+    while ((1 << lnb) < NB) ++lnb;
+    csh = (span ? 32 - __builtin_clz(span) : 0) - lnb;  // bits of the span beyond the log2(NB) a bucket index has
+    if (csh < 0) csh = 0;
+  }
   uint32_t rb[SPT], rs[SPT];
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
-    rb[j] = VIRT ? (cl[j] - v_base) >> v_rshift : cl[j] >> rshift;
+    rb[j] = (cl[j] - cbase) >> csh;
     rs[j] = 0u;
     if ((okm >> j) & 1u) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
   }

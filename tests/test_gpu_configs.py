@@ -315,3 +315,35 @@ def test_partitioned_and_radix_sort_matchers_agree(oracle, forest_paths):
     finally:
         part.close()
         radix.close()
+
+
+def test_forests_whose_top_tests_never_hold(ctx, oracle):
+    """Tests that compare a pixel with itself never set their bit: the codes' top bits are then constant and every match of
+    a row falls into the same top-bit range.  The join divides the range the row's matched codes really span (not the
+    forest's nominal code width) into its rank buckets, so such forests neither lose order nor walk long buckets."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    rng = np.random.default_rng(99)
+    for live, dead_first in ((18, False), (11, False), (20, True)):
+        lines = ["6"]
+        t = 0
+        for fern in range(6):
+            lines.append("%d l 5" % fern)
+            for k in range(5):
+                dead = (t < 30 - live) if dead_first else (t >= live)
+                ix, iy, jx, jy = rng.integers(-13, 14, 4)
+                if dead:
+                    jx, jy = ix, iy
+                lines.append("%d %d %d %d %d 0" % (k, ix, iy, jx, jy))
+                t += 1
+        text = "\n".join(lines)
+        for (W, H, s_, D) in [(1024, 80, 2, 14), (272, 61, 5, 6)]:
+            L, R = synth_pair(W, H, s_, D)
+            st, fm = g.parse_forest(text, W, H)
+            rc, f = oracle.parse_forest_text(text, W, H)
+            ctx.set_forest(fm)
+            for epi in (True, False):
+                want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, 128, 1, epi))
+                got, n, ncand, st = ctx.match_pair(L, R, gset(epi, 5, 128, 1))
+                assert (nl, nr) == ncand and n == len(want)
+                assert np.array_equal(got, want.astype(got.dtype))
