@@ -63,6 +63,24 @@ inline GpcDivW make_divw(int W) {
   return d;
 }
 
+// ndb::Hashmatch's bucket of a 64-bit state (y << 32 | code) % 214673 (hashmatch.hpp:252-263) without 64-bit division:
+// 2^32 mod 214673 = 4585, and x mod 214673 for a 32-bit x by a multiply-high whose quotient is at most one short
+// (checked on the host for every 32-bit x and for 5e7 random states).
+#define HM_BUCKETS 214673u
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t hm_mod(uint32_t x) {
+  const uint32_t q = __umulhi(x, 2622360303u) >> 17;  // floor(2^49 / 214673)
+  uint32_t r = x - q * HM_BUCKETS;
+  if (r >= HM_BUCKETS) r -= HM_BUCKETS;
+  return r;
+}
+__device__ __forceinline__ uint32_t hm_bucket(uint32_t code, uint32_t y) {  // y < 2^30 / 16
+  uint32_t t = hm_mod((y < HM_BUCKETS ? y : hm_mod(y)) * 4585u) + hm_mod(code);
+  if (t >= HM_BUCKETS) t -= HM_BUCKETS;
+  return t;
+}
+#endif
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }

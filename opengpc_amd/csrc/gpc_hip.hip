@@ -23,6 +23,7 @@
 #include "k_global.h"
 #include "k_hash.h"
 #include "k_hashtable.h"
+#include "k_htjoin.h"
 #include "k_partition.h"
 #include "k_preprocess.h"
 #include "k_rowjoin.h"
@@ -648,7 +649,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    hipLaunchKernelGGL(gpc::k_gp_hist, cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
+    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
@@ -663,7 +664,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
-    hipLaunchKernelGGL(gpc::k_gp_scatter, cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+    hipLaunchKernelGGL((gpc::k_gp_scatter<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                        (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
@@ -750,11 +751,88 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
   return GPC_OK;
 }
 
+// useHashtable mode by partition into bins of 1024 buckets + one workgroup per bin (k_htjoin.h).  *done = false when a bin
+// holds more records than the workgroup's LDS (the overflow word, read back at the end: one stream synchronisation per
+// call); whatever was written is then overwritten by the radix path.
+int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int npairs, const gpc_settings* s, int mode,
+                            const uint8_t* d_cand, void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand, bool* done) {
+  *done = false;
+  if (H >= HTJ_MAXH) return GPC_OK;  // positions are packed y << 14 | x
+  gpc::GpLayout L = {};
+  L.nbins = (int)((HM_BUCKETS + HTJ_BUCKETS - 1) / HTJ_BUCKETS);  // 210
+  L.epi = s->epipolar_mode ? 1 : 0;
+  const int rows = H - 2 * GPC_R;
+  L.rows_per_chunk = rows >= 64 ? 16 : (rows + 3) / 4;
+  L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
+  const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
+  const size_t cnt_ints = (size_t)npairs * L.nbins;
+  CHK(ensure(c, c->gpart, sizeof(int32_t) * (tab_ints + cnt_ints + 4)));
+  CHK(ensure(c, c->staged, sizeof(uint2) * (size_t)(g.nmax / 2) * npairs));
+  if (!c->h_flag) HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
+  int32_t* tabs = (int32_t*)c->gpart.p;
+  int32_t* bincnt = tabs + tab_ints;
+  int32_t* d_flag = bincnt + cnt_ints;
+  const uint32_t* codes = (const uint32_t*)c->codes.p;
+  const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;
+  uint32_t* keys = (uint32_t*)c->gkeys[0].p;
+  uint32_t* vals = (uint32_t*)c->gvals[0].p;
+  dim3 cgrid(L.nchunk, 2, npairs);
+  {
+    Timed t(c, KID_GLOBAL_KEYS);
+    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
+    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
+                       (long)L.nbins * L.nchunk);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    Timed t(c, KID_GLOBAL_SORT);
+    hipLaunchKernelGGL((gpc::k_gp_scatter<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                       (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    HIPCHK(c, hipGetLastError());
+  }
+  {
+    Timed t(c, KID_GLOBAL_MATCH);
+    gpc::HtjArgs a;
+    a.keys = keys;
+    a.vals = vals;
+    a.tabs = tabs;
+    a.stats = (const int32_t*)c->stats.p;
+    a.staged = (uint2*)c->staged.p;
+    a.bincnt = bincnt;
+    a.overflow = d_flag;
+    a.recs = g.bs.recs;
+    a.nbins = L.nbins;
+    a.nchunk = L.nchunk;
+    a.epi = L.epi;
+    a.disp_high = s->disp_high;
+    a.vtol = s->vertical_tolerance;
+    a.apply_filter = (mode == 0);
+    a.dw = make_divw(W);
+    const size_t lds = (size_t)8 * HTJ_CAP;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_ht_join), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    hipLaunchKernelGGL(gpc::k_ht_join, dim3(L.nbins, npairs), dim3(HTJ_THREADS), lds, c->stream, a);
+    hipLaunchKernelGGL(gpc::k_ht_gather, dim3((L.nbins + HTG_BINS - 1) / HTG_BINS, npairs), dim3(RM_THREADS), 0, c->stream, a,
+                       mode, d_out, g.bs.out, cap, d_counts, d_ncand);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *done = (*c->h_flag == 0);
+  return GPC_OK;
+}
+
 // useHashtable mode (hashmatch.hpp): stable radix sort by bucket id + one thread per bucket (k_hashtable.h)
 int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, int mode, const uint8_t* d_cand,
                         void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand) {
   GlobalPlan g;
   CHK(plan_global(c, W, H, npairs, mode, cap, true, g));
+  if (!c->no_partition) {
+    bool done = false;
+    CHK(run_hashtable_partition(c, g, W, H, npairs, s, mode, d_cand, d_out, cap, d_counts, d_ncand, &done));
+    if (done) return GPC_OK;
+  }
   const int apply_filter = (mode == 0);
   const int epi = s->epipolar_mode ? 1 : 0;
   const uint32_t* codes = (const uint32_t*)c->codes.p;
@@ -1714,6 +1792,14 @@ extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
   return GPC_OK;
 }
 // the same for the phases of k_hash
+extern "C" int gpc_hip_debug_htjoin_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
+  if (!c || !out16) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(gpc::g_hj_stamps), 16 * sizeof(unsigned long long)));
+  const unsigned long long zero[16] = {0};
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_hj_stamps), zero, sizeof zero));
+  return GPC_OK;
+}
 extern "C" int gpc_hip_debug_hash_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return GPC_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -22,7 +22,6 @@
 
 namespace gpc {
 
-#define HM_BUCKETS 214673u
 #define HM_CAP 10
 
 // skey[i] = state % 214673, sval[i] = i  for the N records (code, side<<31|k) in insertion order;
@@ -59,22 +58,26 @@ __global__ __launch_bounds__(256) void k_ht_bucket_ids(const uint32_t* __restric
 // given as bit masks so that the walk itself touches no memory:
 //   eq bit u = entries u and u+1 hold the same state,  df bit u = they come from different images.
 // Returns the mask of u for which the pair (entry u = source, entry u+1 = target) is reported.
+// The reference's walk, position by position:
+//     i = 0; while (i < n) { p = i++; if (i < n && eq[p]) { if (df[p]) { if (i + 1 >= n || !eq[i]) report p;
+//                                                                       if (i + 1 < n && i + 2 >= n) break; }   // "last triplet"
+//                                                          else if (i + 1 < n && df[i]) ++i; } }               // skip a false pair
+// without the loop: a position p is jumped over iff p - 1 was visited, eq[p-1], !df[p-1], df[p] and p + 1 < n (a
+// recurrence on one bit per position); a visited p with eq[p] & df[p] reports unless eq[p+1] with p + 2 < n; such a p
+// at n - 3 ends the walk before n - 2.  Checked against the loop for every (n, eq, df) on the host.
 __device__ __forceinline__ uint32_t ht_walk_bits(uint32_t eq, uint32_t df, int n) {
-  uint32_t emit = 0u;
-  int i = 0;
-  while (i < n) {
-    const int p = i;
-    ++i;
-    if (i < n && ((eq >> p) & 1u)) {
-      if ((df >> p) & 1u) {
-        const bool e = (i + 1 < n) ? !((eq >> i) & 1u) : true;
-        if (e) emit |= 1u << p;
-        if (i + 1 < n && i + 2 >= n) break;  // "last triplet": the reference leaves the bucket
-      } else if (i + 1 < n && ((df >> i) & 1u)) {
-        ++i;  // skip over a false pair
-      }
-    }
-  }
+  if (n < 2) return 0u;
+  const uint32_t valid1 = (1u << (n - 1)) - 1u;  // p + 1 < n
+  const uint32_t valid2 = (1u << (n - 2)) - 1u;  // p + 2 < n
+  eq &= valid1;
+  df &= valid1;
+  const uint32_t jump = (eq << 1) & ~(df << 1) & df;
+  uint32_t v = 1u;
+#pragma unroll
+  for (int p = 1; p < HM_CAP; ++p) v |= (~((v >> (p - 1)) & (jump >> p)) & 1u) << p;
+  const uint32_t hit = v & eq & df;
+  uint32_t emit = hit & ~((eq >> 1) & valid2);
+  if (n >= 3 && ((hit >> (n - 3)) & 1u)) emit &= ~(1u << (n - 2));
   return emit;
 }
 

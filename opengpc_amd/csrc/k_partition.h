@@ -39,9 +39,17 @@ namespace gpc {
 // misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
+  int epi;                       // HT only: the state carries the row (epipolar mode)
   long ps;                       // ints per pair in the plan blocks
   int o_off, o_rowcnt, o_misc;
 };
+// Which bin a record goes to.  HT (hash-table matcher, k_htjoin.h): the top bits of its Hashmatch bucket.
+#define HTJ_LBITS 10  // buckets per bin = 1024: one per thread of the joining workgroup
+template <bool HT>
+__device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout& g) {
+  if (HT) return hm_bucket(code, g.epi ? (uint32_t)y : 0u) >> HTJ_LBITS;
+  return code >> g.bshift;
+}
 #define GP_NPARTS 0
 #define GP_OVERFLOW 1
 #define GP_LASTR 2
@@ -50,6 +58,7 @@ struct GpLayout {
 // place that way): a workgroup counts the records of its chunk of rows per bin in LDS, the table is scanned, and the
 // scatter hands out positions from an LDS copy of its chunk's starts.
 // grid: (nchunk, 2, npairs)
+template <bool HT>
 __global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
                                                         const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                         int32_t* __restrict__ tabs, GpLayout g) {
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restri
     const uint8_t* crow = cand ? cand + img + (long)y * W : nullptr;
     for (int x = threadIdx.x; x < W; x += GP_THREADS) {
       const uint32_t c = row[x];
-      if (g_is_record(c, crow, x, W)) atomicAdd(&s_cnt[c >> g.bshift], 1);
+      if (g_is_record(c, crow, x, W)) atomicAdd(&s_cnt[gp_bin<HT>(c, y, g)], 1);
     }
   }
   __syncthreads();
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
 // The chunk's pixels go through in tiles of GP_TILE: the tile's records are first put in bin order in LDS, then
 // written out by consecutive threads, so that every bin's run of a tile leaves as one contiguous piece.
 #define GP_TILE 4096
+template <bool HT>
 __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
                                                            const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                            const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
   __shared__ int s_tcnt[GP_MAXBINS];     // records of the tile per bin, then their first place in the tile
   __shared__ int s_gofs[GP_MAXBINS];     // global position of the tile's first record of a bin minus its place in the tile
   __shared__ uint32_t s_key[GP_TILE], s_val[GP_TILE];
+  __shared__ uint8_t s_bin[HT ? GP_TILE : 4];  // HT: the bin is not a shift of the key
   __shared__ uint32_t s_wsum[4];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
   for (int q0 = y0 * W; q0 < y1 * W; q0 += GP_TILE) {
     if (tid < GP_MAXBINS) s_tcnt[tid] = 0;
     __syncthreads();
-    uint32_t c[PPT], pix[PPT];
+    uint32_t c[PPT], pix[PPT], bin[PPT];
     int lr[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -218,7 +229,10 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
       if (q < y1 * W) {
         c[i] = im[q];
         const int yy = divw((uint32_t)q, wd), x = q - yy * W;
-        if (g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, x, W)) lr[i] = atomicAdd(&s_tcnt[c[i] >> g.bshift], 1);
+        if (g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, x, W)) {
+          bin[i] = gp_bin<HT>(c[i], yy, g);
+          lr[i] = atomicAdd(&s_tcnt[bin[i]], 1);
+        }
       }
     }
     __syncthreads();
@@ -239,9 +253,10 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
 #pragma unroll
     for (int i = 0; i < PPT; ++i)
       if (lr[i] >= 0) {
-        const int place = s_tcnt[c[i] >> g.bshift] + lr[i];
+        const int place = s_tcnt[bin[i]] + lr[i];
         s_key[place] = c[i];
         s_val[place] = pix[i];
+        if (HT) s_bin[place] = (uint8_t)bin[i];
       }
     ntile = (int)(s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]);
     if (tid < g.nbins) s_gofs[tid] = s_cur[tid] - s_tcnt[tid];
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
       const int j = i * GP_THREADS + tid;
       if (j < ntile) {
         const uint32_t kk = s_key[j];
-        const int pos = s_gofs[kk >> g.bshift] + j;
+        const int pos = s_gofs[HT ? (uint32_t)s_bin[j] : kk >> g.bshift] + j;
         k[pos] = kk;
         v[pos] = s_val[j];
       }

@@ -312,6 +312,27 @@ def test_partitioned_and_radix_sort_matchers_agree(oracle, forest_paths):
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[1].sum() > 0
         for i in range(5):
             assert np.array_equal(a[0][i, : a[1][i]], b[0][i, : b[1][i]])
+        # the hash-table matcher has the same pair of implementations (k_htjoin.h: bins of 1024 buckets; k_hashtable.h:
+        # radix sort by bucket id).  The stripes put more records into one bin than a workgroup holds: fallback.
+        for fo, L, R in cases:
+            H, W = L.shape
+            rc, f = oracle.read_forest(forest_paths[fo], W, H)
+            for ctx in (part, radix):
+                ctx.load_forest(forest_paths[fo], W, H)
+            for epi, disp, vtol in ((True, 128, 1), (False, 128, 1), (True, 6, 0)):
+                want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, disp, vtol, epi, True))
+                for ctx in (part, radix):
+                    got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, disp, vtol, epi, True, 1))
+                    assert st == 0 and (nl, nr) == ncand and n == len(want)
+                    assert np.array_equal(got, want.astype(got.dtype))
+        for ctx in (part, radix):
+            ctx.load_forest(forest_paths["tau"], 528, 90)
+        hset = g.Settings(5, 128, 1, True, True, 1)
+        a = part.match_batch(np.stack(Ls), np.stack(Rs), hset, 40000)
+        b = radix.match_batch(np.stack(Ls), np.stack(Rs), hset, 40000)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[1].sum() > 0
+        for i in range(5):
+            assert np.array_equal(a[0][i, : a[1][i]], b[0][i, : b[1][i]])
     finally:
         part.close()
         radix.close()

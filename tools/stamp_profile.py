@@ -42,6 +42,20 @@ def main():
     for i, name in enumerate(PHASES):
         print("  %-14s %6.1f %%   %8.0f ticks/wg" % (name, 100.0 * buf[i] / tot, buf[i] / nblk))
     print("  total %.0f ticks/wg" % (tot / nblk))
+    HJ = ["bin bounds (scalar loads)", "records arrive", "buckets + counts", "scan", "placed", "10-cap", "ranks",
+          "list order + links", "walk + scan", "output"]
+    hs = g.Settings(5, 128, 1, True, True, 1)
+    Bh = min(B, 32)
+    ctx.match_batch(L[:Bh], R[:Bh], hs, cap)
+    ctx.L.gpc_hip_debug_htjoin_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    ctx.L.gpc_hip_debug_htjoin_stamps(ctx.h, buf)
+    ctx.match_batch(L[:Bh], R[:Bh], hs, cap)
+    ctx.L.gpc_hip_debug_htjoin_stamps(ctx.h, buf)
+    nwg = Bh * len([b for b in range(210) if (b & 15) == 5])
+    print("k_ht_join phases (s_memtime ticks of thread 0, 10 ns each, per sampled workgroup):")
+    for i, name in enumerate(HJ):
+        print("  %-28s %8.1f ticks" % (name, buf[i] / nwg))
+    print("  total %.1f ticks" % (sum(buf[i] for i in range(len(HJ))) / nwg))
     ctx.L.gpc_hip_debug_hash_stamps.argtypes = [C.c_void_p, C.c_void_p]
     ctx.L.gpc_hip_debug_hash_stamps(ctx.h, buf)
     tot = sum(buf[i] for i in range(len(HASH_PHASES)))
