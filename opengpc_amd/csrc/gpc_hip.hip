@@ -752,8 +752,8 @@ int run_global_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_setting
 }
 
 // useHashtable mode by partition into bins of 1024 buckets + one workgroup per bin (k_htjoin.h).  *done = false when a bin
-// holds more records than the workgroup's LDS (the overflow word, read back at the end: one stream synchronisation per
-// call); whatever was written is then overwritten by the radix path.
+// holds more records than one workgroup takes (the overflow word, read back after the histogram: one stream
+// synchronisation per call); nothing has been written then and the caller takes the radix path.
 int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int npairs, const gpc_settings* s, int mode,
                             const uint8_t* d_cand, void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand, bool* done) {
   *done = false;
@@ -783,8 +783,13 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
+    hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
+                       (const int32_t*)c->stats.p, L.nbins, L.nchunk, d_flag);
     HIPCHK(c, hipGetLastError());
   }
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
     hipLaunchKernelGGL((gpc::k_gp_scatter<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
@@ -800,7 +805,6 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     a.stats = (const int32_t*)c->stats.p;
     a.staged = (uint2*)c->staged.p;
     a.bincnt = bincnt;
-    a.overflow = d_flag;
     a.recs = g.bs.recs;
     a.nbins = L.nbins;
     a.nchunk = L.nchunk;
@@ -817,9 +821,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
                        mode, d_out, g.bs.out, cap, d_counts, d_ncand);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *done = (*c->h_flag == 0);
+  *done = true;
   return GPC_OK;
 }
 

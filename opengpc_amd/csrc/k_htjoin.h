@@ -16,7 +16,7 @@
 //      block scan of the emitted pairs gives their places in the bin's output;
 //   3. k_ht_gather: bins in ascending order = bucket order -> gpc_support / gpc_correspondence.
 // A bin that holds more than HTJ_CAP records (images beyond ~0.8 M candidates, or heavily repeated states) raises
-// the overflow word and the host takes the radix path.
+// the overflow word (k_ht_check, right after the histogram) and the host takes the radix path.
 #pragma once
 #include "gpc_device.h"
 #include "k_hashtable.h"
@@ -38,7 +38,6 @@ struct HtjArgs {
   const int32_t* stats;
   uint2* staged;           // [npairs][recs / 2]: (y << 14 | x left, right) of a bin's pairs from the bin's left start on
   int32_t* bincnt;         // [npairs][nbins]: pairs per bin
-  int32_t* overflow;       // one word per batch
   long recs;
   int nbins, nchunk, epi, disp_high, vtol, apply_filter;
   GpcDivW dw;
@@ -77,6 +76,20 @@ __device__ unsigned long long g_hj_stamps[16];
 #define HTJ_MAXH (1 << 17)
 __device__ __forceinline__ uint32_t htj_row(uint32_t kv) { return (kv >> HTJ_XBITS) & 0x1FFFFu; }
 #define HTJ_SIDE 0x80000000u
+
+// Raises the overflow word if some bin holds more records than one workgroup takes (known once the chunk tables are
+// scanned: before anything is scattered).  grid: (npairs); nbins <= 256 threads
+__global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __restrict__ stats, int nbins, int nchunk,
+                           int32_t* __restrict__ overflow) {
+  const int pair = blockIdx.x, bin = threadIdx.x;
+  if (bin >= nbins) return;
+  const int32_t* tl = tabs + (long)(pair * 2) * nbins * nchunk;
+  const int32_t* tr = tl + (long)nbins * nchunk;
+  const int NL = stats[(pair * 2) * GPC_STAT_STRIDE + GPC_STAT_NCAND], NR = stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+  const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
+  const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
+  if (nl + nr > HTJ_CAP) atomicOr(overflow, 1);
+}
 
 // rank += (oy : oc : okv) < (y : c : kv) as 96-bit numbers, i.e. "state, then insertion order": a borrow chain.
 __device__ __forceinline__ int htj_rank_add(int rank, uint32_t oy, uint32_t oc, uint32_t okv, uint32_t y, uint32_t c,
@@ -125,11 +138,8 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
   const int nr = (bin + 1 < a.nbins ? tr[(long)(bin + 1) * a.nchunk] : NR) - orr;
   const int n = nl + nr;
   int32_t* bincnt = a.bincnt + (long)pair * a.nbins;
-  if (n > HTJ_CAP) {  // block-uniform
-    if (tid == 0) {
-      atomicOr(a.overflow, 1);
-      bincnt[bin] = 0;
-    }
+  if (n > HTJ_CAP) {  // block-uniform; k_ht_check has sent such a batch to the radix path already
+    if (tid == 0) bincnt[bin] = 0;
     return;
   }
   HJ_STAMP(0);  // bin bounds (scalar loads)
