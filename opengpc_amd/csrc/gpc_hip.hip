@@ -152,6 +152,7 @@ struct gpc_hip_ctx {
   DevBuf gpart;       // partition plan of the non-epipolar matcher (k_partition.h) + one overflow word for the batch
   int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
   int no_partition = 0;       // GPC_HIP_NO_PARTITION: always take the radix-sort path (A/B checks)
+  int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
   DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
@@ -627,7 +628,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   L.target = 1400;  // records per side a partition aims at: a third of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
   L.pmax = g.nmax / L.target + 2;  // cuts happen where a running count <= nmax passes a multiple of the target
   const int rows = H - 2 * GPC_R;
-  L.rows_per_chunk = rows >= 64 ? 16 : (rows + 3) / 4;  // >= 4 chunks per image, ~1.7 k workgroups at 32 pairs of 436 rows
+  L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;  // >= 4 chunks per image
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
   L.o_off = 0;
   L.o_rowcnt = L.o_off + 2 * (L.pmax + 1);
@@ -649,7 +650,8 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
+    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
+                       make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
@@ -762,7 +764,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   L.nbins = (int)((HM_BUCKETS + HTJ_BUCKETS - 1) / HTJ_BUCKETS);  // 210
   L.epi = s->epipolar_mode ? 1 : 0;
   const int rows = H - 2 * GPC_R;
-  L.rows_per_chunk = rows >= 64 ? 16 : (rows + 3) / 4;
+  L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
   const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
   const size_t cnt_ints = (size_t)npairs * L.nbins;
@@ -780,7 +782,8 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L);
+    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
+                       make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
@@ -946,6 +949,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   c->no_partition = getenv("GPC_HIP_NO_PARTITION") != nullptr;
+  if (const char* e = getenv("GPC_HIP_ROWS_PER_CHUNK")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) c->rows_per_chunk = v;
+  }
   const char* ck = getenv("GPC_HIP_CHUNK");
   if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");

@@ -61,20 +61,24 @@ __device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout&
 template <bool HT>
 __global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
                                                         const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
-                                                        int32_t* __restrict__ tabs, GpLayout g) {
+                                                        int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd) {
   __shared__ int s_cnt[GP_MAXBINS];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
   for (int i = threadIdx.x; i < g.nbins; i += GP_THREADS) s_cnt[i] = 0;
   __syncthreads();
   const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
   const long img = pair * codes_stride + (long)side * H * W;
-  for (int y = y0; y < y1; ++y) {
-    const uint32_t* row = codes + img + (long)y * W;
-    const uint8_t* crow = cand ? cand + img + (long)y * W : nullptr;
-    for (int x = threadIdx.x; x < W; x += GP_THREADS) {
-      const uint32_t c = row[x];
-      if (g_is_record(c, crow, x, W)) atomicAdd(&s_cnt[gp_bin<HT>(c, y, g)], 1);
-    }
+  const uint32_t* im = codes + img;
+  const uint8_t* cm = cand ? cand + img : nullptr;
+  // the chunk's rows are one contiguous stretch of the code image (margin pixels hold the sentinel): four pixels of
+  // one row per thread and step (W is a multiple of 16)
+  for (int q = y0 * W + 4 * (int)threadIdx.x; q < y1 * W; q += 4 * GP_THREADS) {
+    const uint4 c4 = *reinterpret_cast<const uint4*>(im + q);
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    const int yy = (HT || cm) ? divw((uint32_t)q, wd) : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (g_is_record(c[k], cm ? cm + (long)yy * W : nullptr, q + k - yy * W, W)) atomicAdd(&s_cnt[gp_bin<HT>(c[k], yy, g)], 1);
   }
   __syncthreads();
   int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
@@ -199,13 +203,13 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
                                                            const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long recs) {
   __shared__ int s_cur[GP_MAXBINS];      // where the chunk's next record of a bin goes (global position)
-  __shared__ int s_tcnt[GP_MAXBINS];     // records of the tile per bin, then their first place in the tile
+  __shared__ __attribute__((aligned(16))) int s_tcnt[GP_MAXBINS];  // records of the tile per bin, then their first place in the tile
   __shared__ int s_gofs[GP_MAXBINS];     // global position of the tile's first record of a bin minus its place in the tile
   __shared__ uint32_t s_key[GP_TILE], s_val[GP_TILE];
   __shared__ uint8_t s_bin[HT ? GP_TILE : 4];  // HT: the bin is not a shift of the key
-  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_wsum[1];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
   if (tid < g.nbins) s_cur[tid] = tab[tid * g.nchunk + chunk];
   uint32_t* k = keys + pair * recs + side * (recs / 2);
@@ -215,41 +219,45 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
   const uint32_t* im = codes + img;
   const uint8_t* cm = cand ? cand + img : nullptr;
   constexpr int PPT = GP_TILE / GP_THREADS;
-  for (int q0 = y0 * W; q0 < y1 * W; q0 += GP_TILE) {
+  static_assert(PPT == 4, "a thread takes four consecutive pixels of a tile with one 16-byte load");
+  const int qend = y1 * W;
+  uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+  if (y0 * W + 4 * tid < qend) nxt = *reinterpret_cast<const uint4*>(im + y0 * W + 4 * tid);
+  for (int q0 = y0 * W; q0 < qend; q0 += GP_TILE) {
     if (tid < GP_MAXBINS) s_tcnt[tid] = 0;
     __syncthreads();
-    uint32_t c[PPT], pix[PPT], bin[PPT];
+    const int qb = q0 + 4 * tid;  // this thread's four pixels of the tile (one row: W is a multiple of 16)
+    const uint4 c4 = nxt;
+    if (qb + GP_TILE < qend) nxt = *reinterpret_cast<const uint4*>(im + qb + GP_TILE);  // the next tile's, under this one's work
+    uint32_t c[PPT] = {c4.x, c4.y, c4.z, c4.w}, pix[PPT], bin[PPT];
     int lr[PPT];
+    const int yy = (qb < qend && (HT || cm)) ? divw((uint32_t)qb, wd) : 0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int q = q0 + i * GP_THREADS + tid;
+      const int q = qb + i;
       lr[i] = -1;
       pix[i] = (uint32_t)q;
-      c[i] = 0u;
-      if (q < y1 * W) {
-        c[i] = im[q];
-        const int yy = divw((uint32_t)q, wd), x = q - yy * W;
-        if (g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, x, W)) {
-          bin[i] = gp_bin<HT>(c[i], yy, g);
-          lr[i] = atomicAdd(&s_tcnt[bin[i]], 1);
-        }
+      bin[i] = 0u;
+      if (qb < qend && g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, q - yy * W, W)) {
+        bin[i] = gp_bin<HT>(c[i], yy, g);
+        lr[i] = atomicAdd(&s_tcnt[bin[i]], 1);
       }
     }
     __syncthreads();
-    int ntile = 0;
-    if (tid < GP_MAXBINS) {  // 256 bins: four waves scan, the first ones' sums carry over
-      const uint32_t cnt = (uint32_t)s_tcnt[tid];
-      const uint32_t incl = wave_incl_scan(cnt);
-      if (lane == 63) s_wsum[wave] = incl;
-      s_tcnt[tid] = (int)(incl - cnt);  // exclusive within the wave for now
+    if (tid < 64) {  // 256 bins: one wave scans, four consecutive bins per lane
+      int4 cnt = *reinterpret_cast<int4*>(&s_tcnt[4 * tid]);
+      const uint32_t sum = (uint32_t)(cnt.x + cnt.y + cnt.z + cnt.w);
+      const uint32_t incl = wave_incl_scan(sum);
+      int4 ex;
+      ex.x = (int)(incl - sum);
+      ex.y = ex.x + cnt.x;
+      ex.z = ex.y + cnt.y;
+      ex.w = ex.z + cnt.z;
+      *reinterpret_cast<int4*>(&s_tcnt[4 * tid]) = ex;  // first place of the bin in the tile
+      if (tid == 63) s_wsum[0] = incl;
     }
     __syncthreads();
-    if (tid < GP_MAXBINS) {
-      int base = 0;
-      for (int w = 0; w < wave; ++w) base += (int)s_wsum[w];
-      s_tcnt[tid] += base;  // first place of the bin in the tile
-    }
-    __syncthreads();
+    const int ntile = (int)s_wsum[0];
 #pragma unroll
     for (int i = 0; i < PPT; ++i)
       if (lr[i] >= 0) {
@@ -258,12 +266,11 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
         s_val[place] = pix[i];
         if (HT) s_bin[place] = (uint8_t)bin[i];
       }
-    ntile = (int)(s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]);
     if (tid < g.nbins) s_gofs[tid] = s_cur[tid] - s_tcnt[tid];
     __syncthreads();
     if (tid < g.nbins) {  // advance the chunk's cursors by what this tile holds of the bin
-      const int nxt = (tid + 1 < GP_MAXBINS) ? s_tcnt[tid + 1] : ntile;
-      s_cur[tid] += nxt - s_tcnt[tid];
+      const int nx = (tid + 1 < GP_MAXBINS) ? s_tcnt[tid + 1] : ntile;
+      s_cur[tid] += nx - s_tcnt[tid];
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
