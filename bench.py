@@ -369,7 +369,7 @@ def main():
                     same = same and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
                 pcie["identical_to_device_path"] = same
                 pcie["measured_in"] = "child process without torch (the library's own ROCm runtime)"
-                pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 7 calls"
+                pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 15 calls after 5 untimed"
             except Exception as e:  # the headline does not depend on it
                 pcie = None
                 print("bench.py: pcie_inclusive child failed: %r" % (e,), file=sys.stderr)
@@ -379,10 +379,10 @@ def main():
             Lp[:] = Lh
             Rp[:] = Rh
             outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
-            for _ in range(2):
+            for _ in range(3):
                 o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
             tt = []
-            for _ in range(5):
+            for _ in range(9):
                 t0 = time.perf_counter()
                 o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
                 tt.append(time.perf_counter() - t0)
