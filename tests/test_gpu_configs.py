@@ -368,3 +368,20 @@ def test_forests_whose_top_tests_never_hold(ctx, oracle):
                 got, n, ncand, st = ctx.match_pair(L, R, gset(epi, 5, 128, 1))
                 assert (nl, nr) == ncand and n == len(want)
                 assert np.array_equal(got, want.astype(got.dtype))
+
+
+def test_very_tall_image_in_the_device_wide_modes(ctx, oracle, forest_paths):
+    """The partitioned hash-table matcher packs a position as y << 14 | x and hands images of 2^17 rows or more to the
+    radix-sort matcher (k_hashtable.h); the row of a 64-bit state `y << 32 | code` stays exact either way."""
+    import opengpc_amd as g
+    W, H = 48, (1 << 17) + 40
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (H, W + 8), dtype=np.uint8)
+    L, R = np.ascontiguousarray(base[:, 4:4 + W]), np.ascontiguousarray(base[:, 1:1 + W])
+    rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+    ctx.load_forest(forest_paths["zero"], W, H)
+    for epi, ht in ((True, True), (False, True), (False, False), (True, False)):
+        want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, 128, 1, epi, ht))
+        got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, ht, 1))
+        assert st == 0 and (nl, nr) == ncand and n == len(want) and n > 0
+        assert np.array_equal(got, want.astype(got.dtype))
