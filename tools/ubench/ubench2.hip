@@ -105,6 +105,15 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
         REP8(LDSRD("ds_read_u8", "v"))
         r0 += q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
       }
+    } else if (MODE == 28 || MODE == 29) {  // two adjacent dwords per lane with ONE instruction, 8-byte stride; 29: only 4-byte aligned
+      const uint32_t addr = (uint32_t)(uintptr_t)lds + (tid & 63) * 8 + ((it & 3) << 11) + (MODE == 29 ? 4 : 0);
+      u32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+      REP8(asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:1\n\tds_read2_b32 %1, %8 offset0:64 offset1:65\n\t"
+                        "ds_read2_b32 %2, %8 offset0:128 offset1:129\n\tds_read2_b32 %3, %8 offset0:192 offset1:193\n\t"
+                        "ds_read2_b32 %4, %8 offset0:16 offset1:17\n\tds_read2_b32 %5, %8 offset0:80 offset1:81\n\t"
+                        "ds_read2_b32 %6, %8 offset0:144 offset1:145\n\tds_read2_b32 %7, %8 offset0:208 offset1:209\n\ts_waitcnt lgkmcnt(0)"
+                        : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(addr));)
+      r0 += q0.x + q1.y + q2.x + q3.y + q4.x + q5.y + q6.x + q7.y;
     } else if (MODE == 24) {  // LDS reads beside VALU (the hash kernel's mix: 2 ds_read_b32 per 6 VALU)
       const uint32_t addr = (uint32_t)(uintptr_t)lds + (tid & 63) * 4 + ((it & 3) << 11);
       uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
@@ -153,7 +162,7 @@ int main() {
     {"v_cmp+v_addc (pairs)", 15, 64}, {"swar test mix (8 valu)", 16, 64},
     {"ds_read_b32 linear", 20, 64}, {"ds_read_b64 linear", 21, 64}, {"ds_read_b128 linear", 22, 64}, {"ds_read_u8 linear", 23, 64},
     {"2 ds_read_b32 + 6 valu", 24, 64}, {"ds_read_b64 addr%8==4", 25, 64}, {"ds_read_b128 addr%16==4", 26, 64},
-    {"ds_read_b128 addr%16==8", 27, 64}};
+    {"ds_read_b128 addr%16==8", 27, 64}, {"ds_read2_b32 adjacent", 28, 64}, {"ds_read2_b32 adj addr%8==4", 29, 64}};
   for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     printf("== %d workgroups of 256 threads per CU (%d waves/SIMD)\n", wg_per_cu, wg_per_cu);
@@ -162,7 +171,7 @@ int main() {
       switch (c.mode) {
 #define RUN(M) case M: r = run<M>(d_out, d_cyc, blocks, iters); break;
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16)
-        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27)
+        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29)
         default: continue;
       }
       // cycles per instruction as one wave sees it, and per SIMD (divide by the waves sharing the SIMD);
