@@ -650,7 +650,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
+    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
                        make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
@@ -666,7 +666,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
-    hipLaunchKernelGGL((gpc::k_gp_scatter<false>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+    hipLaunchKernelGGL((gpc::k_gp_scatter<false>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                        (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
@@ -782,7 +782,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
+    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
                        make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
@@ -795,7 +795,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
-    hipLaunchKernelGGL((gpc::k_gp_scatter<true>), cgrid, dim3(GP_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+    hipLaunchKernelGGL((gpc::k_gp_scatter<true>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                        (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }

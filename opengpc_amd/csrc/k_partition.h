@@ -33,6 +33,9 @@ namespace gpc {
                           // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS)
 #define GP_NB 4096          // records per side a partition may hold: k_row_join<4, 1024>
 #define GP_THREADS 1024
+#ifndef GPS_THREADS
+#define GPS_THREADS 1024    // threads of a histogram / scatter workgroup (scatter per 32 pairs: 1024 -> 96 us, 512 -> 128, 256 -> 183: shorter runs)
+#endif
 // tabs: [npairs * 2][nbins * nchunk] int32 -- records per (bin, chunk of rows) of one image, bin-major; after the
 //       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
 // plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][rowcnt : pmax][misc : 8]
@@ -59,12 +62,12 @@ __device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout&
 // scatter hands out positions from an LDS copy of its chunk's starts.
 // grid: (nchunk, 2, npairs)
 template <bool HT>
-__global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
+__global__ __launch_bounds__(GPS_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
                                                         const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                         int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd) {
   __shared__ int s_cnt[GP_MAXBINS];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
-  for (int i = threadIdx.x; i < g.nbins; i += GP_THREADS) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < g.nbins; i += GPS_THREADS) s_cnt[i] = 0;
   __syncthreads();
   const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
   const long img = pair * codes_stride + (long)side * H * W;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restri
   const uint8_t* cm = cand ? cand + img : nullptr;
   // the chunk's rows are one contiguous stretch of the code image (margin pixels hold the sentinel): four pixels of
   // one row per thread and step (W is a multiple of 16)
-  for (int q = y0 * W + 4 * (int)threadIdx.x; q < y1 * W; q += 4 * GP_THREADS) {
+  for (int q = y0 * W + 4 * (int)threadIdx.x; q < y1 * W; q += 4 * GPS_THREADS) {
     const uint4 c4 = *reinterpret_cast<const uint4*>(im + q);
     const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
     const int yy = (HT || cm) ? divw((uint32_t)q, wd) : 0;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_hist(const uint32_t* __restri
   }
   __syncthreads();
   int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
-  for (int i = threadIdx.x; i < g.nbins; i += GP_THREADS) tab[i * g.nchunk + chunk] = s_cnt[i];
+  for (int i = threadIdx.x; i < g.nbins; i += GPS_THREADS) tab[i * g.nchunk + chunk] = s_cnt[i];
 }
 
 // exclusive block scan of one value per thread (1024 threads); returns the exclusive prefix, *total gets the sum
@@ -196,9 +199,12 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
 // grid: (nchunk, 2, npairs); records of side s of a pair live at keys / vals + pair * recs + s * (recs / 2).
 // The chunk's pixels go through in tiles of GP_TILE: the tile's records are first put in bin order in LDS, then
 // written out by consecutive threads, so that every bin's run of a tile leaves as one contiguous piece.
-#define GP_TILE 4096
+#ifndef GP_GROUPS
+#define GP_GROUPS 2   // per 32 pairs, scatter of the non-epipolar / hash-table mode: 1 -> 96 / 97 us, 2 -> 81 / 93, 3 -> 86 / 97 (LDS: one workgroup per CU)
+#endif
+#define GP_TILE (4 * GP_GROUPS * GPS_THREADS)
 template <bool HT>
-__global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
+__global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
                                                            const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                            const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long recs) {
@@ -211,36 +217,48 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
   const int tid = threadIdx.x;
   const int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
-  if (tid < g.nbins) s_cur[tid] = tab[tid * g.nchunk + chunk];
+  for (int i = tid; i < g.nbins; i += GPS_THREADS) s_cur[i] = tab[i * g.nchunk + chunk];
   uint32_t* k = keys + pair * recs + side * (recs / 2);
   uint32_t* v = vals + pair * recs + side * (recs / 2);
   const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
   const long img = pair * codes_stride + (long)side * H * W;
   const uint32_t* im = codes + img;
   const uint8_t* cm = cand ? cand + img : nullptr;
-  constexpr int PPT = GP_TILE / GP_THREADS;
-  static_assert(PPT == 4, "a thread takes four consecutive pixels of a tile with one 16-byte load");
+  constexpr int PPT = GP_TILE / GPS_THREADS;
+  constexpr int NG = GP_GROUPS;  // groups of four consecutive pixels (one 16-byte load each) a thread takes per tile
   const int qend = y1 * W;
-  uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
-  if (y0 * W + 4 * tid < qend) nxt = *reinterpret_cast<const uint4*>(im + y0 * W + 4 * tid);
-  for (int q0 = y0 * W; q0 < qend; q0 += GP_TILE) {
-    if (tid < GP_MAXBINS) s_tcnt[tid] = 0;
-    __syncthreads();
-    const int qb = q0 + 4 * tid;  // this thread's four pixels of the tile (one row: W is a multiple of 16)
-    const uint4 c4 = nxt;
-    if (qb + GP_TILE < qend) nxt = *reinterpret_cast<const uint4*>(im + qb + GP_TILE);  // the next tile's, under this one's work
-    uint32_t c[PPT] = {c4.x, c4.y, c4.z, c4.w}, pix[PPT], bin[PPT];
-    int lr[PPT];
-    const int yy = (qb < qend && (HT || cm)) ? divw((uint32_t)qb, wd) : 0;
+  uint4 nxt[NG];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int q = qb + i;
-      lr[i] = -1;
-      pix[i] = (uint32_t)q;
-      bin[i] = 0u;
-      if (qb < qend && g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, q - yy * W, W)) {
-        bin[i] = gp_bin<HT>(c[i], yy, g);
-        lr[i] = atomicAdd(&s_tcnt[bin[i]], 1);
+  for (int gi = 0; gi < NG; ++gi) {
+    const int qb = y0 * W + 4 * (gi * GPS_THREADS + tid);
+    nxt[gi] = make_uint4(0u, 0u, 0u, 0u);
+    if (qb < qend) nxt[gi] = *reinterpret_cast<const uint4*>(im + qb);
+  }
+  for (int q0 = y0 * W; q0 < qend; q0 += GP_TILE) {
+    for (int i = tid; i < GP_MAXBINS; i += GPS_THREADS) s_tcnt[i] = 0;
+    __syncthreads();
+    uint32_t c[PPT], pix[PPT], bin[PPT];
+    int lr[PPT];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int qb = q0 + 4 * (gi * GPS_THREADS + tid);  // four pixels of one row: W is a multiple of 16
+      const uint4 c4 = nxt[gi];
+      if (qb + GP_TILE < qend) nxt[gi] = *reinterpret_cast<const uint4*>(im + qb + GP_TILE);  // the next tile's, under this one's work
+      c[4 * gi + 0] = c4.x;
+      c[4 * gi + 1] = c4.y;
+      c[4 * gi + 2] = c4.z;
+      c[4 * gi + 3] = c4.w;
+      const int yy = (qb < qend && (HT || cm)) ? divw((uint32_t)qb, wd) : 0;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int i = 4 * gi + k4, q = qb + k4;
+        lr[i] = -1;
+        pix[i] = (uint32_t)q;
+        bin[i] = 0u;
+        if (qb < qend && g_is_record(c[i], cm ? cm + (long)yy * W : nullptr, q - yy * W, W)) {
+          bin[i] = gp_bin<HT>(c[i], yy, g);
+          lr[i] = atomicAdd(&s_tcnt[bin[i]], 1);
+        }
       }
     }
     __syncthreads();
@@ -266,15 +284,15 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_scatter(const uint32_t* __res
         s_val[place] = pix[i];
         if (HT) s_bin[place] = (uint8_t)bin[i];
       }
-    if (tid < g.nbins) s_gofs[tid] = s_cur[tid] - s_tcnt[tid];
+    for (int i = tid; i < g.nbins; i += GPS_THREADS) s_gofs[i] = s_cur[i] - s_tcnt[i];
     __syncthreads();
-    if (tid < g.nbins) {  // advance the chunk's cursors by what this tile holds of the bin
-      const int nx = (tid + 1 < GP_MAXBINS) ? s_tcnt[tid + 1] : ntile;
-      s_cur[tid] += nx - s_tcnt[tid];
+    for (int i = tid; i < g.nbins; i += GPS_THREADS) {  // advance the chunk's cursors by what this tile holds of the bin
+      const int nx = (i + 1 < GP_MAXBINS) ? s_tcnt[i + 1] : ntile;
+      s_cur[i] += nx - s_tcnt[i];
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int j = i * GP_THREADS + tid;
+      const int j = i * GPS_THREADS + tid;
       if (j < ntile) {
         const uint32_t kk = s_key[j];
         const int pos = s_gofs[HT ? (uint32_t)s_bin[j] : kk >> g.bshift] + j;
