@@ -143,12 +143,15 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     return;
   }
   HJ_STAMP(0);  // bin bounds (scalar loads)
-  const uint32_t* kl = a.keys + pair * a.recs + ol;
-  const uint32_t* kr = a.keys + pair * a.recs + a.recs / 2 + orr - nl;
-  const uint32_t* vl = a.vals + pair * a.recs + ol;
-  const uint32_t* vr = a.vals + pair * a.recs + a.recs / 2 + orr - nl;
+  // one base per array and a 32-bit index (left records at ol + i, right ones at recs / 2 + orr + i - nl): per-lane
+  // 64-bit pointers would cost two registers per record and array
+  const uint32_t* kb = a.keys + pair * a.recs;
+  const uint32_t* vb = a.vals + pair * a.recs;
+  const uint32_t roff = (uint32_t)(a.recs / 2) + (uint32_t)orr - (uint32_t)nl;
 
-  // ---- the bin's records -> registers (loads first, the counters are cleared under them)
+  // ---- the bin's records -> registers (loads first, the counters are cleared under them).
+  // (Two or three bins per workgroup with the next bin's records prefetched under the last phases were tried: 291 vs
+  // 241 us per 32 pairs -- the eight prefetched values per thread do not fit beside the rank phase at 64 VGPRs.)
   uint32_t code[HTJ_RPT], kv[HTJ_RPT];
 #pragma unroll
   for (int j = 0; j < HTJ_RPT; ++j) {
@@ -157,8 +160,9 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     kv[j] = 0xFFFFFFFFu;  // no record
     if (i < n) {
       const bool right = i >= nl;
-      code[j] = (right ? kr : kl)[i];
-      const uint32_t pix = (right ? vr : vl)[i];
+      const uint32_t idx = (uint32_t)i + (right ? roff : (uint32_t)ol);
+      code[j] = kb[idx];
+      const uint32_t pix = vb[idx];
       const uint32_t y = (uint32_t)divw(pix, a.dw);
       kv[j] = (right ? HTJ_SIDE : 0u) | (y << HTJ_XBITS) | (pix - y * (uint32_t)a.dw.W);
     }
