@@ -622,11 +622,17 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   const bool wide = wide_codes(c);
   const int bits = wide ? 32 : code_bits(c);
   gpc::GpLayout L;
-  int lb = bits < 8 ? bits : 8;  // GP_MAXBINS
+  // 256 bins (8 top code bits) up to ~1 M record slots per pair; 512 / 1024 for larger images, so that a bin of a textured
+  // image still holds about a partition's worth of records (the scatter's runs get shorter: k_partition.h)
+  int lb = 8;
+  while (lb < 10 && (double)g.nmax * 0.7 / (double)(1 << lb) > 2800.0) ++lb;
+  if (lb > bits) lb = bits;
   L.nbins = 1 << lb;
   L.bshift = bits - lb;
   L.target = 1400;  // records per side a partition aims at: a third of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
-  L.pmax = g.nmax / L.target + 2;  // cuts happen where a running count <= nmax passes a multiple of the target
+  // cuts happen where a running count <= nmax passes a multiple of the target, and around bins of more than
+  // GP_NB - target records (k_gp_plan); the join's grid is what the plan really made (read back with the overflow word)
+  L.pmax = g.nmax / L.target + 2 * (g.nmax / (GP_NB - L.target)) + 2;
   const int rows = H - 2 * GPC_R;
   L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;  // >= 4 chunks per image
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
@@ -650,8 +656,12 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<false>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
-                       make_divw(W));
+    if (L.nbins > 256)
+      hipLaunchKernelGGL((gpc::k_gp_hist<false, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                         tabs, L, make_divw(W));
+    else
+      hipLaunchKernelGGL((gpc::k_gp_hist<false, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                         tabs, L, make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
@@ -661,13 +671,18 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
                        (const int32_t*)c->stats.p, part, L, d_flag);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (*c->h_flag) return GPC_OK;  // the caller sorts instead
+  if (c->h_flag[0]) return GPC_OK;  // the caller sorts instead
+  const int maxparts = c->h_flag[1] > 0 ? c->h_flag[1] : 1;
   {
     Timed t(c, KID_GLOBAL_SORT);
-    hipLaunchKernelGGL((gpc::k_gp_scatter<false>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
-                       (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    if (L.nbins > 256)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<false, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    else
+      hipLaunchKernelGGL((gpc::k_gp_scatter<false, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
   {
@@ -688,7 +703,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     const int log2s = 13;  // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU
     const size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
     const int apply_filter = (mode == 0);
-    const dim3 jgrid(L.pmax, npairs);
+    const dim3 jgrid(maxparts, npairs);
 #define LAUNCH_VJOIN(WIDE)                                                                                              \
   do {                                                                                                                  \
     const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<4, 1024, WIDE, true>);                              \
@@ -699,7 +714,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   } while (0)
     if (wide) LAUNCH_VJOIN(true); else LAUNCH_VJOIN(false);
 #undef LAUNCH_VJOIN
-    hipLaunchKernelGGL(gpc::k_gp_gather, dim3((L.pmax + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
+    hipLaunchKernelGGL(gpc::k_gp_gather, dim3((maxparts + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
                        (const uint32_t*)c->staged.p, (const int32_t*)part, L, (const uint32_t*)vals, g.bs.recs, make_divw(W),
                        mode, d_out, g.bs.out, cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
     HIPCHK(c, hipGetLastError());
@@ -761,7 +776,11 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   *done = false;
   if (H >= HTJ_MAXH) return GPC_OK;  // positions are packed y << 14 | x
   gpc::GpLayout L = {};
-  L.nbins = (int)((HM_BUCKETS + HTJ_BUCKETS - 1) / HTJ_BUCKETS);  // 210
+  // bins of 1024 buckets (210 of them) up to ~1 M record slots per pair; 512 / 256 buckets per bin for larger images
+  int lbits = HTJ_LBITS;
+  while (lbits > 8 && (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0) --lbits;  // a bin holds up to HTJ_CAP = 4096
+  L.bshift = lbits;
+  L.nbins = (int)((HM_BUCKETS + (1u << lbits) - 1) >> lbits);  // 210 / 420 / 839
   L.epi = s->epipolar_mode ? 1 : 0;
   const int rows = H - 2 * GPC_R;
   L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;
@@ -782,8 +801,12 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL((gpc::k_gp_hist<true>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes, tabs, L,
-                       make_divw(W));
+    if (L.nbins > 256)
+      hipLaunchKernelGGL((gpc::k_gp_hist<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                         tabs, L, make_divw(W));
+    else
+      hipLaunchKernelGGL((gpc::k_gp_hist<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                         tabs, L, make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
@@ -795,8 +818,12 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
-    hipLaunchKernelGGL((gpc::k_gp_scatter<true>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
-                       (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    if (L.nbins > 256)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    else
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
   {
@@ -811,6 +838,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     a.recs = g.bs.recs;
     a.nbins = L.nbins;
     a.nchunk = L.nchunk;
+    a.lbits = lbits;
     a.epi = L.epi;
     a.disp_high = s->disp_high;
     a.vtol = s->vertical_tolerance;

@@ -40,6 +40,7 @@ struct HtjArgs {
   int32_t* bincnt;         // [npairs][nbins]: pairs per bin
   long recs;
   int nbins, nchunk, epi, disp_high, vtol, apply_filter;
+  int lbits;               // log2(buckets per bin): HTJ_LBITS, or less for large images (then only the first threads own a bucket)
   GpcDivW dw;
 };
 
@@ -78,17 +79,18 @@ __device__ __forceinline__ uint32_t htj_row(uint32_t kv) { return (kv >> HTJ_XBI
 #define HTJ_SIDE 0x80000000u
 
 // Raises the overflow word if some bin holds more records than one workgroup takes (known once the chunk tables are
-// scanned: before anything is scattered).  grid: (npairs); nbins <= 256 threads
+// scanned: before anything is scattered).  grid: (npairs); 256 threads
 __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __restrict__ stats, int nbins, int nchunk,
                            int32_t* __restrict__ overflow) {
-  const int pair = blockIdx.x, bin = threadIdx.x;
-  if (bin >= nbins) return;
+  const int pair = blockIdx.x;
   const int32_t* tl = tabs + (long)(pair * 2) * nbins * nchunk;
   const int32_t* tr = tl + (long)nbins * nchunk;
   const int NL = stats[(pair * 2) * GPC_STAT_STRIDE + GPC_STAT_NCAND], NR = stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-  const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
-  const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
-  if (nl + nr > HTJ_CAP) atomicOr(overflow, 1);
+  for (int bin = threadIdx.x; bin < nbins; bin += blockDim.x) {
+    const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
+    const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
+    if (nl + nr > HTJ_CAP) atomicOr(overflow, 1);
+  }
 }
 
 // rank += (oy : oc : okv) < (y : c : kv) as 96-bit numbers, i.e. "state, then insertion order": a borrow chain.
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     place[j] = 0;
     if (kv[j] != 0xFFFFFFFFu) {
       yy[j] = a.epi ? htj_row(kv[j]) : 0u;
-      lb[j] = (int)(hm_bucket(code[j], yy[j]) & (HTJ_BUCKETS - 1));
+      lb[j] = (int)(hm_bucket(code[j], yy[j]) & ((1u << a.lbits) - 1u));
       place[j] = (int)atomicAdd(&s_cs[lb[j]], 1u);  // arrival rank within the bucket
     }
   }

@@ -23,14 +23,17 @@
 // positions, and the one place the reference's order among EQUAL codes matters (tail quirk Q2: first of two equal
 // targets in mask order) takes the smaller pixel index explicitly.
 #pragma once
+#include <type_traits>
 #include "gpc_device.h"
 #include "k_global.h"
 #include "k_rows.h"
 
 namespace gpc {
 
-#define GP_MAXBINS 256    // bins = 8 top code bits: more destinations make the scatter's runs too short to coalesce (measured per 32 pairs:
-                          // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS)
+#define GP_MAXBINS 1024   // histogram / scatter kernels come for 256 and 1024 bins (template MB).  256 = 8 top code bits is the
+                          // rule: more destinations make the scatter's runs too short to coalesce (measured per 32 pairs:
+                          // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS);
+                          // images beyond ~1 M pixels take 512 or 1024 so that a bin still fits one workgroup's LDS
 #define GP_NB 4096          // records per side a partition may hold: k_row_join<4, 1024>
 #define GP_THREADS 1024
 #ifndef GPS_THREADS
@@ -40,6 +43,7 @@ namespace gpc {
 //       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
 // plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][rowcnt : pmax][misc : 8]
 // misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
+// batch words (after the plan blocks): [0] some pair overflowed, [1] largest number of partitions of a pair
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
   int epi;                       // HT only: the state carries the row (epipolar mode)
@@ -50,7 +54,7 @@ struct GpLayout {
 #define HTJ_LBITS 10  // buckets per bin = 1024: one per thread of the joining workgroup
 template <bool HT>
 __device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout& g) {
-  if (HT) return hm_bucket(code, g.epi ? (uint32_t)y : 0u) >> HTJ_LBITS;
+  if (HT) return hm_bucket(code, g.epi ? (uint32_t)y : 0u) >> g.bshift;  // bshift = log2(buckets per bin), 8 .. HTJ_LBITS
   return code >> g.bshift;
 }
 #define GP_NPARTS 0
@@ -61,11 +65,11 @@ __device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout&
 // place that way): a workgroup counts the records of its chunk of rows per bin in LDS, the table is scanned, and the
 // scatter hands out positions from an LDS copy of its chunk's starts.
 // grid: (nchunk, 2, npairs)
-template <bool HT>
+template <bool HT, int MB>
 __global__ __launch_bounds__(GPS_THREADS) void k_gp_hist(const uint32_t* __restrict__ codes,
                                                         const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                         int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd) {
-  __shared__ int s_cnt[GP_MAXBINS];
+  __shared__ int s_cnt[MB];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
   for (int i = threadIdx.x; i < g.nbins; i += GPS_THREADS) s_cnt[i] = 0;
   __syncthreads();
@@ -149,19 +153,29 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
     }
   }
   __syncthreads();
-  // a bin starts a partition when its raw number differs from its predecessor's; partition id = cuts before it
+  // A bin starts a partition when its raw number differs from its predecessor's (the predecessor crossed a multiple of
+  // the target), or when it or its predecessor is BIG (more than GP_NB - target records on a side): a big bin stands
+  // alone, and a run of other bins holds at most target - 1 + (GP_NB - target) records -- so a partition exceeds GP_NB
+  // only if a single bin does.  Partition id = cuts before it.
+  const uint32_t bigsz = (uint32_t)(GP_NB - g.target);
+  auto starts = [&](int b) {
+    if (b == 0 || s_praw[b] != s_praw[b - 1]) return true;
+    const uint32_t mb = (uint32_t)max(s_sl[b + 1] - s_sl[b], s_sr[b + 1] - s_sr[b]);
+    const uint32_t mp = (uint32_t)max(s_sl[b] - s_sl[b - 1], s_sr[b] - s_sr[b - 1]);
+    return mb > bigsz || mp > bigsz;
+  };
   uint32_t ncut = 0;
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int b = tid * bpt + i;
-    if (i < bpt && b < g.nbins) ncut += (b == 0 || s_praw[b] != s_praw[b - 1]) ? 1u : 0u;
+    if (i < bpt && b < g.nbins) ncut += starts(b) ? 1u : 0u;
   }
   uint32_t nparts;
   uint32_t id = gp_block_exscan(ncut, s_w, &nparts);
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int b = tid * bpt + i;
-    if (i < bpt && b < g.nbins && (b == 0 || s_praw[b] != s_praw[b - 1])) {
+    if (i < bpt && b < g.nbins && starts(b)) {
       if ((int)id <= g.pmax) {
         s_off[id] = s_sl[b];
         s_off[g.pmax + 1 + id] = s_sr[b];
@@ -193,7 +207,10 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
   }
   for (int o = 32; o > 0; o >>= 1) last_r = max(last_r, __shfl_xor(last_r, o));
   if ((tid & 63) == 0 && last_r >= 0) atomicMax(&misc[GP_LASTR], last_r);
-  if (tid == 0) misc[GP_NPARTS] = too_many ? 0 : (int32_t)nparts;
+  if (tid == 0) {
+    misc[GP_NPARTS] = too_many ? 0 : (int32_t)nparts;
+    if (!too_many) atomicMax(batch_overflow + 1, (int32_t)nparts);  // the batch's largest partition count: the join's grid
+  }
 }
 
 // grid: (nchunk, 2, npairs); records of side s of a pair live at keys / vals + pair * recs + s * (recs / 2).
@@ -203,16 +220,17 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
 #define GP_GROUPS 2   // per 32 pairs, scatter of the non-epipolar / hash-table mode: 1 -> 96 / 97 us, 2 -> 81 / 93, 3 -> 86 / 97 (LDS: one workgroup per CU)
 #endif
 #define GP_TILE (4 * GP_GROUPS * GPS_THREADS)
-template <bool HT>
+template <bool HT, int MB>
 __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
                                                            const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                            const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long recs) {
-  __shared__ int s_cur[GP_MAXBINS];      // where the chunk's next record of a bin goes (global position)
-  __shared__ __attribute__((aligned(16))) int s_tcnt[GP_MAXBINS];  // records of the tile per bin, then their first place in the tile
-  __shared__ int s_gofs[GP_MAXBINS];     // global position of the tile's first record of a bin minus its place in the tile
+  typedef typename std::conditional<(MB > 256), uint16_t, uint8_t>::type bin_t;
+  __shared__ int s_cur[MB];      // where the chunk's next record of a bin goes (global position)
+  __shared__ __attribute__((aligned(16))) int s_tcnt[MB];  // records of the tile per bin, then their first place in the tile
+  __shared__ int s_gofs[MB];     // global position of the tile's first record of a bin minus its place in the tile
   __shared__ uint32_t s_key[GP_TILE], s_val[GP_TILE];
-  __shared__ uint8_t s_bin[HT ? GP_TILE : 4];  // HT: the bin is not a shift of the key
+  __shared__ bin_t s_bin[HT ? GP_TILE : 4];  // HT: the bin is not a shift of the key
   __shared__ uint32_t s_wsum[1];
   const int chunk = blockIdx.x, side = blockIdx.y, pair = blockIdx.z;
   const int tid = threadIdx.x;
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
     if (qb < qend) nxt[gi] = *reinterpret_cast<const uint4*>(im + qb);
   }
   for (int q0 = y0 * W; q0 < qend; q0 += GP_TILE) {
-    for (int i = tid; i < GP_MAXBINS; i += GPS_THREADS) s_tcnt[i] = 0;
+    for (int i = tid; i < MB; i += GPS_THREADS) s_tcnt[i] = 0;
     __syncthreads();
     uint32_t c[PPT], pix[PPT], bin[PPT];
     int lr[PPT];
@@ -262,16 +280,27 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
       }
     }
     __syncthreads();
-    if (tid < 64) {  // 256 bins: one wave scans, four consecutive bins per lane
-      int4 cnt = *reinterpret_cast<int4*>(&s_tcnt[4 * tid]);
-      const uint32_t sum = (uint32_t)(cnt.x + cnt.y + cnt.z + cnt.w);
+    if (tid < 64) {  // one wave scans: MB / 64 consecutive bins per lane
+      constexpr int Q = MB / 256;  // groups of four bins per lane
+      int4 cnt[Q];
+      uint32_t sum = 0u;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        cnt[q] = *reinterpret_cast<int4*>(&s_tcnt[4 * (Q * tid + q)]);
+        sum += (uint32_t)(cnt[q].x + cnt[q].y + cnt[q].z + cnt[q].w);
+      }
       const uint32_t incl = wave_incl_scan(sum);
-      int4 ex;
-      ex.x = (int)(incl - sum);
-      ex.y = ex.x + cnt.x;
-      ex.z = ex.y + cnt.y;
-      ex.w = ex.z + cnt.z;
-      *reinterpret_cast<int4*>(&s_tcnt[4 * tid]) = ex;  // first place of the bin in the tile
+      int run = (int)(incl - sum);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        int4 ex;
+        ex.x = run;
+        ex.y = ex.x + cnt[q].x;
+        ex.z = ex.y + cnt[q].y;
+        ex.w = ex.z + cnt[q].z;
+        run = ex.w + cnt[q].w;
+        *reinterpret_cast<int4*>(&s_tcnt[4 * (Q * tid + q)]) = ex;  // first place of the bin in the tile
+      }
       if (tid == 63) s_wsum[0] = incl;
     }
     __syncthreads();
@@ -282,12 +311,12 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
         const int place = s_tcnt[bin[i]] + lr[i];
         s_key[place] = c[i];
         s_val[place] = pix[i];
-        if (HT) s_bin[place] = (uint8_t)bin[i];
+        if (HT) s_bin[place] = (bin_t)bin[i];
       }
     for (int i = tid; i < g.nbins; i += GPS_THREADS) s_gofs[i] = s_cur[i] - s_tcnt[i];
     __syncthreads();
     for (int i = tid; i < g.nbins; i += GPS_THREADS) {  // advance the chunk's cursors by what this tile holds of the bin
-      const int nx = (i + 1 < GP_MAXBINS) ? s_tcnt[i + 1] : ntile;
+      const int nx = (i + 1 < MB) ? s_tcnt[i + 1] : ntile;
       s_cur[i] += nx - s_tcnt[i];
     }
 #pragma unroll

@@ -385,3 +385,23 @@ def test_very_tall_image_in_the_device_wide_modes(ctx, oracle, forest_paths):
         got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, ht, 1))
         assert st == 0 and (nl, nr) == ncand and n == len(want) and n > 0
         assert np.array_equal(got, want.astype(got.dtype))
+
+
+def test_large_images_in_the_device_wide_modes(ctx, forest_paths):
+    """1280x720 and 1920x1080 (BASELINE configs[2]'s size) through the non-epipolar sort-matcher and the hash-table
+    matcher.  The partition kernels take 512 / 1024 code-range bins and bins of 256 buckets there, so that a bin still
+    fits one workgroup (720p: both partitioned matchers run; 1080p with the Tau forest: one code range holds more than a
+    workgroup takes and the radix path runs instead) -- the results are the oracle's either way."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    from oracle.pyoracle import Oracle
+    fast = Oracle(fast=True)
+    for (W, H, s_, D, fo) in ((1280, 720, 3, 30, "zero"), (1920, 1080, 1, 40, "tau")):
+        L, R = synth_pair(W, H, s_, D)
+        rc, f = fast.read_forest(forest_paths[fo], W, H)
+        ctx.load_forest(forest_paths[fo], W, H)
+        for epi, ht in ((False, False), (True, True), (False, True)):
+            want, nl, nr = fast.match_pair(L, R, f, sparsematch_settings(5, 128, 1, epi, ht))
+            got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, ht, 1))
+            assert st == 0 and (nl, nr) == ncand and n == len(want) and n > 100000
+            assert np.array_equal(got, want.astype(got.dtype))

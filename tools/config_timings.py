@@ -26,6 +26,8 @@ CONFIGS = [
     ("C2 single 1024x436 Zero epipolar hashtable", 1024, 436, "defaultZeroForest.txt", 0, 24, 1, True, True),
     ("C2 batch32 1024x436 Zero global (non-epipolar)", 1024, 436, "defaultZeroForest.txt", 0, 24, 32, False, False),
     ("C2 batch32 1024x436 Zero epipolar hashtable", 1024, 436, "defaultZeroForest.txt", 0, 24, 32, True, True),
+    ("C3 batch8 1920x1080 Tau global (non-epipolar)", 1920, 1080, "defaultTauForest.txt", 1, 40, 8, False, False),
+    ("C3 batch8 1920x1080 Tau epipolar hashtable", 1920, 1080, "defaultTauForest.txt", 1, 40, 8, True, True),
 ]
 
 
