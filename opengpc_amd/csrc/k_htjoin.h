@@ -9,13 +9,14 @@
 // order.  Insertion order is the order of (side, pixel index), which every record carries -- so nothing has to be
 // kept stable on the way:
 //   1. k_gp_hist<true> / k_g_scan / k_gp_scatter<true> (k_partition.h) partition the records of either image by the top
-//      bits of their bucket: 210 bins of 1024 buckets, ~1360 records per side and bin for a 1024x436 pair;
+//      bits of their bucket: 210 bins of 1024 buckets, ~1360 records per side and bin for a 1024x436 pair (larger
+//      images: 420 / 839 bins of 512 / 256 buckets, HtjArgs::lbits);
 //   2. k_ht_join, one workgroup per bin: counting sort of the bin's records by bucket in LDS (arrival order), every
 //      record counts the records of its bucket inserted before it (kept iff < 10), then its rank among the kept ones
 //      and its successor; thread b replays the walk of bucket b's list (ht_walk_bits, k_hashtable.h) on link bits, a
 //      block scan of the emitted pairs gives their places in the bin's output;
 //   3. k_ht_gather: bins in ascending order = bucket order -> gpc_support / gpc_correspondence.
-// A bin that holds more than HTJ_CAP records (images beyond ~0.8 M candidates, or heavily repeated states) raises
+// A bin that holds more than HTJ_CAP records (images beyond ~2.5 M candidates, or heavily repeated states) raises
 // the overflow word (k_ht_check, right after the histogram) and the host takes the radix path.
 #pragma once
 #include "gpc_device.h"

@@ -9,13 +9,15 @@
 // PARTITIONED into contiguous code ranges of a few hundred to ~1400 records per side, and every partition goes
 // through the same LDS hash join + counting rank as an image row of the epipolar matcher (k_rowjoin.h, VIRT):
 // partitions in ascending order and ranks inside a partition give the reference's output order.
-//   1. k_gp_hist     fine histogram of the top code bits (<= 4096 bins) per chunk of rows, in LDS; k_g_scan over the
-//                    (bin, chunk) table gives every chunk the start of its records in every bin;
+//   1. k_gp_hist     histogram of the top code bits (256 bins; 512 / 1024 for images beyond ~1 M pixels) per chunk of
+//                    rows, in LDS; k_g_scan over the (bin, chunk) table gives every chunk the start of its records in
+//                    every bin;
 //   2. k_gp_plan     per pair: cuts where the running count max(nL, nR) passes a multiple of the target
-//                    size (so a partition is a run of consecutive bins, adapted to the image's code distribution),
-//                    start positions of every bin and partition, and an OVERFLOW flag when a partition exceeds what
-//                    one workgroup can join (heavily duplicated codes: striped images) -- the host then takes the
-//                    radix-sort path of k_global.h;
+//                    size (so a partition is a run of consecutive bins, adapted to the image's code distribution) and
+//                    around every bin that is large by itself, start positions of every bin and partition, and an
+//                    OVERFLOW flag when a partition exceeds what one workgroup can join (a single bin of more than 4096
+//                    records: heavily duplicated codes, striped images) -- the host then takes the radix-sort path of
+//                    k_global.h;
 //   3. k_gp_scatter  records (code, pixel index) to their bin's stretch (positions from an LDS copy of the chunk's starts);
 //   4. k_row_join<4, 1024, WIDE, true>  one workgroup per partition;
 //   5. k_gp_gather   matches -> gpc_support / gpc_correspondence in partition order.
