@@ -778,7 +778,9 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   gpc::GpLayout L = {};
   // bins of 1024 buckets (210 of them) up to ~1 M record slots per pair; 512 / 256 buckets per bin for larger images
   int lbits = HTJ_LBITS;
-  while (lbits > 8 && (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0) --lbits;  // a bin holds up to HTJ_CAP = 4096
+  while (lbits > 8 && (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0) --lbits;  // a bin holds up to 4096
+  // ... or 8192 records (k_ht_join<8>: one workgroup per CU) where 839 bins are still too few
+  const int rpt = (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0 ? 8 : 4;
   L.bshift = lbits;
   L.nbins = (int)((HM_BUCKETS + (1u << lbits) - 1) >> lbits);  // 210 / 420 / 839
   L.epi = s->epipolar_mode ? 1 : 0;
@@ -810,7 +812,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
     hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
-                       (const int32_t*)c->stats.p, L.nbins, L.nchunk, d_flag);
+                       (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * rpt, d_flag);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -844,10 +846,15 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     a.vtol = s->vertical_tolerance;
     a.apply_filter = (mode == 0);
     a.dw = make_divw(W);
-    const size_t lds = (size_t)8 * HTJ_CAP;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_ht_join), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    hipLaunchKernelGGL(gpc::k_ht_join, dim3(L.nbins, npairs), dim3(HTJ_THREADS), lds, c->stream, a);
+    const size_t lds = (size_t)8 * HTJ_THREADS * rpt;
+#define LAUNCH_HTJ(RPT)                                                                                                  \
+  do {                                                                                                                   \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_ht_join<RPT>),                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+    hipLaunchKernelGGL(gpc::k_ht_join<RPT>, dim3(L.nbins, npairs), dim3(HTJ_THREADS), lds, c->stream, a);                \
+  } while (0)
+    if (rpt == 8) LAUNCH_HTJ(8); else LAUNCH_HTJ(4);
+#undef LAUNCH_HTJ
     hipLaunchKernelGGL(gpc::k_ht_gather, dim3((L.nbins + HTG_BINS - 1) / HTG_BINS, npairs), dim3(RM_THREADS), 0, c->stream, a,
                        mode, d_out, g.bs.out, cap, d_counts, d_ncand);
     HIPCHK(c, hipGetLastError());

@@ -27,10 +27,11 @@ namespace gpc {
 
 #define HTJ_THREADS 1024
 #define HTJ_BUCKETS (1 << HTJ_LBITS)  // == HTJ_THREADS: thread b owns bucket b of the bin
-#ifndef HTJ_RPT
-#define HTJ_RPT 4                     // records per thread
-#endif
-#define HTJ_CAP (HTJ_THREADS * HTJ_RPT)  // records of both images a bin may hold: 8 bytes of LDS each
+// k_ht_join<RPT>: RPT records per thread; a bin may hold HTJ_THREADS * RPT records of both images, 8 bytes of LDS each.
+// RPT = 4 (64 VGPRs, two workgroups per CU) is the rule; RPT = 8 (one workgroup per CU) takes the bins of images
+// whose 839 bins of 256 buckets would still overflow 4096 records (1920x1080).
+template <int RPT>
+struct HtjOcc { static constexpr int kWaves = RPT <= 4 ? 8 : 4; };
 
 struct HtjArgs {
   const uint32_t* keys;    // [npairs][recs]: codes, left image's records then (at recs / 2) the right image's, by bin
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t htj_row(uint32_t kv) { return (kv >> HTJ_XBI
 // Raises the overflow word if some bin holds more records than one workgroup takes (known once the chunk tables are
 // scanned: before anything is scattered).  grid: (npairs); 256 threads
 __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __restrict__ stats, int nbins, int nchunk,
-                           int32_t* __restrict__ overflow) {
+                           int cap, int32_t* __restrict__ overflow) {
   const int pair = blockIdx.x;
   const int32_t* tl = tabs + (long)(pair * 2) * nbins * nchunk;
   const int32_t* tr = tl + (long)nbins * nchunk;
@@ -90,7 +91,7 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
   for (int bin = threadIdx.x; bin < nbins; bin += blockDim.x) {
     const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
     const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
-    if (nl + nr > HTJ_CAP) atomicOr(overflow, 1);
+    if (nl + nr > cap) atomicOr(overflow, 1);
   }
 }
 
@@ -122,8 +123,10 @@ __device__ __forceinline__ int htj_rank_add(int rank, uint32_t oy, uint32_t oc, 
 // strided pass + a DPP minimum; insertion order = order of kv), the ten winners ranked among themselves.
 // The kernel is bound by the number of LDS operations (random addresses, 32 waves per CU): a record is one 8-byte
 // LDS element, a bucket's start and count one word.
-// grid: (nbins, npairs); dynamic LDS: 8 * HTJ_CAP bytes
-__global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ht_join(HtjArgs a) {
+// grid: (nbins, npairs); dynamic LDS: 8 * HTJ_THREADS * RPT bytes
+template <int RPT>
+__global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(HtjOcc<RPT>::kWaves, 8))) void k_ht_join(HtjArgs a) {
+  constexpr int HTJ_RPT = RPT, HTJ_CAP = HTJ_THREADS * RPT;
   extern __shared__ __attribute__((aligned(16))) uint2 htj_rec[];  // (code, side << 31 | y << 14 | x), by bucket
   __shared__ uint32_t s_cs[HTJ_BUCKETS];    // records per bucket, then start | count << 16
   __shared__ uint32_t s_bits[HTJ_BUCKETS];  // link bits, then emitted links | first output place << 10
