@@ -630,6 +630,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   L.nbins = 1 << lb;
   L.bshift = bits - lb;
   L.target = 1400;  // records per side a partition aims at: a third of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
+  L.cap = GP_NB;
   // cuts happen where a running count <= nmax passes a multiple of the target, and around bins of more than
   // GP_NB - target records (k_gp_plan); the join's grid is what the plan really made (read back with the overflow word)
   L.pmax = g.nmax / L.target + 2 * (g.nmax / (GP_NB - L.target)) + 2;
@@ -653,6 +654,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   uint32_t* keys = (uint32_t*)c->gkeys[0].p;
   uint32_t* vals = (uint32_t*)c->gvals[0].p;
   dim3 cgrid(L.nchunk, 2, npairs);
+  const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
@@ -664,15 +666,25 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
                          tabs, L, make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
-    const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_gp_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)plan_lds));
     hipLaunchKernelGGL(gpc::k_gp_plan, dim3(npairs), dim3(GP_THREADS), plan_lds, c->stream, (const int32_t*)tabs,
                        (const int32_t*)c->stats.p, part, L, d_flag);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->h_flag[0] && c->h_flag[2] <= 2 * GP_NB) {
+    // Some partition is over-full, but every single bin still fits the 8192-record join (skewed top code bits on a large
+    // image): plan again for that one.
+    L.cap = 2 * GP_NB;
+    HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
+    hipLaunchKernelGGL(gpc::k_gp_plan, dim3(npairs), dim3(GP_THREADS), plan_lds, c->stream, (const int32_t*)tabs,
+                       (const int32_t*)c->stats.p, part, L, d_flag);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (c->h_flag[0]) return GPC_OK;  // the caller sorts instead
   const int maxparts = c->h_flag[1] > 0 ? c->h_flag[1] : 1;
   {
@@ -700,19 +712,24 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     v.pmax = L.pmax;
     v.dw = make_divw(W);
     v.vtol = s->vertical_tolerance;
-    const int log2s = 13;  // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU
+    // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU; 16384 for up to 8192: one workgroup
+    const int log2s = L.cap > GP_NB ? 14 : 13;
     const size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
     const int apply_filter = (mode == 0);
     const dim3 jgrid(maxparts, npairs);
-#define LAUNCH_VJOIN(WIDE)                                                                                              \
+#define LAUNCH_VJOIN(SPT, WIDE)                                                                                         \
   do {                                                                                                                  \
-    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<4, 1024, WIDE, true>);                              \
+    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, 1024, WIDE, true>);                            \
     HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-    hipLaunchKernelGGL((gpc::k_row_join<4, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
+    hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
                        (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v);                                             \
   } while (0)
-    if (wide) LAUNCH_VJOIN(true); else LAUNCH_VJOIN(false);
+    if (L.cap > GP_NB) {
+      if (wide) LAUNCH_VJOIN(8, true); else LAUNCH_VJOIN(8, false);
+    } else {
+      if (wide) LAUNCH_VJOIN(4, true); else LAUNCH_VJOIN(4, false);
+    }
 #undef LAUNCH_VJOIN
     hipLaunchKernelGGL(gpc::k_gp_gather, dim3((maxparts + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
                        (const uint32_t*)c->staged.p, (const int32_t*)part, L, (const uint32_t*)vals, g.bs.recs, make_divw(W),

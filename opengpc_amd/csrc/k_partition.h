@@ -36,7 +36,8 @@ namespace gpc {
                           // rule: more destinations make the scatter's runs too short to coalesce (measured per 32 pairs:
                           // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS);
                           // images beyond ~1 M pixels take 512 or 1024 so that a bin still fits one workgroup's LDS
-#define GP_NB 4096          // records per side a partition may hold: k_row_join<4, 1024>
+#define GP_NB 4096          // records per side a partition may hold: k_row_join<4, 1024> (GpLayout::cap; 8192 with k_row_join<8, 1024>
+                            // where a single bin is larger: skewed top code bits on large images)
 #define GP_THREADS 1024
 #ifndef GPS_THREADS
 #define GPS_THREADS 1024    // threads of a histogram / scatter workgroup (scatter per 32 pairs: 1024 -> 96 us, 512 -> 128, 256 -> 183: shorter runs)
@@ -45,9 +46,11 @@ namespace gpc {
 //       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
 // plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][rowcnt : pmax][misc : 8]
 // misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
-// batch words (after the plan blocks): [0] some pair overflowed, [1] largest number of partitions of a pair
+// batch words (after the plan blocks): [0] some pair overflowed, [1] largest number of partitions of a pair,
+//                                       [2] largest bin (records of one side)
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
+  int cap;                       // records per side a partition may hold
   int epi;                       // HT only: the state carries the row (epipolar mode)
   long ps;                       // ints per pair in the plan blocks
   int o_off, o_rowcnt, o_misc;
@@ -144,6 +147,13 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
     m[i] = in ? (uint32_t)max(s_sl[b + 1] - s_sl[b], s_sr[b + 1] - s_sr[b]) : 0u;
     sm += m[i];
   }
+  {  // the largest bin of the batch: what decides between the 4096- and the 8192-record join and the radix path
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) mx = max(mx, m[i]);
+    mx = wave_max_u32(mx);
+    if ((tid & 63) == 0 && mx) atomicMax(batch_overflow + 2, (int32_t)mx);
+  }
   uint32_t tm;
   uint32_t am = gp_block_exscan(sm, s_w, &tm);
 #pragma unroll
@@ -156,10 +166,10 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
   }
   __syncthreads();
   // A bin starts a partition when its raw number differs from its predecessor's (the predecessor crossed a multiple of
-  // the target), or when it or its predecessor is BIG (more than GP_NB - target records on a side): a big bin stands
-  // alone, and a run of other bins holds at most target - 1 + (GP_NB - target) records -- so a partition exceeds GP_NB
-  // only if a single bin does.  Partition id = cuts before it.
-  const uint32_t bigsz = (uint32_t)(GP_NB - g.target);
+  // the target), or when it or its predecessor is BIG (more than cap - target records on a side): a big bin stands
+  // alone, and a run of other bins holds at most target - 1 + (cap - target) records -- so a partition exceeds the
+  // capacity only if a single bin does.  Partition id = cuts before it.
+  const uint32_t bigsz = (uint32_t)(g.cap - g.target);
   auto starts = [&](int b) {
     if (b == 0 || s_praw[b] != s_praw[b - 1]) return true;
     const uint32_t mb = (uint32_t)max(s_sl[b + 1] - s_sl[b], s_sr[b + 1] - s_sr[b]);
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
       blk[g.o_off + g.pmax + 1 + p] = s_off[g.pmax + 1 + p];
       if (p < (int)nparts) {
         const int nl = s_off[p + 1] - s_off[p], nr = s_off[g.pmax + 1 + p + 1] - s_off[g.pmax + 1 + p];
-        if (nl > GP_NB || nr > GP_NB) over = 1;
+        if (nl > g.cap || nr > g.cap) over = 1;
         if (nr > 0) last_r = p;
       }
     }
