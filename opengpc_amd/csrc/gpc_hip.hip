@@ -153,6 +153,7 @@ struct gpc_hip_ctx {
   int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
   int no_partition = 0;       // GPC_HIP_NO_PARTITION: always take the radix-sort path (A/B checks)
   int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
+  int flat_chunks = 0;        // GPC_HIP_FLAT_CHUNKS: gpc_hip_match_batch with equal chunks only (A/B checks)
   DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
@@ -1001,6 +1002,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   const char* jr = getenv("GPC_HIP_JOIN_RPW");
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   c->no_partition = getenv("GPC_HIP_NO_PARTITION") != nullptr;
+  c->flat_chunks = getenv("GPC_HIP_FLAT_CHUNKS") != nullptr;
   if (const char* e = getenv("GPC_HIP_ROWS_PER_CHUNK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) c->rows_per_chunk = v;
@@ -1475,7 +1477,37 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   const size_t n = (size_t)W * H;
   int chunk = npairs < 4 ? npairs : (npairs / 8 < 1 ? 1 : (npairs / 8 > 16 ? 16 : npairs / 8));
   if (c->chunk_pairs > 0) chunk = c->chunk_pairs < npairs ? c->chunk_pairs : npairs;
-  const int nch = (npairs + chunk - 1) / chunk;
+  // Chunk schedule: full chunks in the middle; the FIRST one is split 1/4 + 3/4 (kernels start after a quarter of an
+  // upload) and the LAST one 1/2 + 1/4 + 1/4 (the tail after the last upload -- its kernels, download and expansion --
+  // covers 4 pairs instead of 16).  Slots are sized for a full chunk.
+  std::vector<int> c_start, c_size;
+  {
+    int rem = npairs, at = 0;
+    auto put = [&](int m) {
+      if (m <= 0) return;
+      c_start.push_back(at);
+      c_size.push_back(m);
+      at += m;
+      rem -= m;
+    };
+    // (chunks of 8 split further cost more per-chunk overhead than they hide: 64 pairs 2.05 vs 1.67 ms; 256 pairs, chunks of
+    // 16: 5.33 vs 5.87 ms)
+    const bool shaped = !c->flat_chunks && chunk >= 16 && npairs >= 4 * chunk;
+    if (shaped) {
+      put(chunk / 4);
+      put(chunk - chunk / 4);
+    }
+    while (rem > chunk) put(chunk);
+    if (shaped && rem >= 4) {
+      const int r = rem;
+      put(r / 2);
+      put(r / 4);
+      put(r - r / 2 - r / 4);
+    } else {
+      put(rem);
+    }
+  }
+  const int nch = (int)c_size.size();
   // (three-byte records x | (x - xR + dispHigh) << xbits were tried for the link: byte stores on the device and a
   // byte shuffle on the host made the call slower, 7.5 vs 6.2 ms per 256 pairs; the link is not the limit any more)
   const size_t rec = 4;
@@ -1510,11 +1542,10 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   uint8_t* d_pk = (uint8_t*)c->packed.p;
   uint8_t* h_pk = (uint8_t*)c->h_stage;
   int status = GPC_OK;
-  auto pairs_of = [&](int k) { return (k * chunk + chunk <= npairs) ? chunk : npairs - k * chunk; };
   int32_t* d_tot = reinterpret_cast<int32_t*>(d_pk + 3 * cb);  // [3][chunk] scratch of k_pair_totals
   // the counts of chunk k are on their way: wait for them, then fetch the chunk's row counts and records in one copy
   auto download = [&](int k) -> int {
-    const int p0 = k * chunk, pc = pairs_of(k);
+    const int p0 = c_start[k], pc = c_size[k];
     HIPCHK(c, hipEventSynchronize(c->e_cnt[k & 3]));
     memcpy(counts + p0, hc + p0, sizeof(int32_t) * pc);
     if (ncand) memcpy(ncand + 2 * p0, hn + 2 * p0, sizeof(int32_t) * 2 * pc);
@@ -1531,7 +1562,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     return GPC_OK;
   };
   auto expand = [&](int k) -> int {
-    const int p0 = k * chunk, pc = pairs_of(k);
+    const int p0 = c_start[k], pc = c_size[k];
     HIPCHK(c, hipEventSynchronize(c->e_out[k & 3]));
     const int parts = c->pool.size() >= 8 ? 4 : 2;
     const uint8_t* slot = h_pk + (size_t)(k & 3) * cb;
@@ -1553,7 +1584,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
     return GPC_OK;
   };
   for (int k = 0; k < nch; ++k) {
-    const int ev = k & 3, p0 = k * chunk, pc = pairs_of(k);
+    const int ev = k & 3, p0 = c_start[k], pc = c_size[k];
     uint8_t* d_l = (uint8_t*)c->raw.p + (size_t)(k & 1) * 2 * n * chunk;
     uint8_t* d_r = d_l + n * chunk;
     if (k >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->e_comp[(k - 2) & 3], 0));  // chunk k-2 has read this slot
