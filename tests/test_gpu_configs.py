@@ -215,7 +215,9 @@ def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
         #  2064 px with dispHigh 4000 needs 12 + 13 bits; dispHigh 0 and 1 are the narrowest disparity fields)
         for (W, H, P, fo, disp) in [(1024, 436, 11, "zero", 128), (272, 61, 37, "tau", 128), (528, 41, 5, "tau", 9),
                                     (2064, 36, 3, "zero", 128), (48, 30, 2, "zero", 128), (2064, 36, 3, "tau", 4000),
-                                    (1024, 60, 4, "zero", 4000), (272, 61, 3, "zero", 0), (272, 61, 3, "zero", 1)]:
+                                    (1024, 60, 4, "zero", 4000), (272, 61, 3, "zero", 0), (272, 61, 3, "zero", 1),
+                                    # 128+ pairs: chunks of 16 with the first one split 4 + 12 and the last 8 + 4 + 4 / ragged
+                                    (96, 40, 131, "zero", 128), (96, 40, 128, "tau", 128)]:
             ctx.load_forest(forest_paths[fo], W, H)
             s = g.Settings(5, disp, 0, True, False, 1)
             Lh, Rh = synth_batch(W, H, [3 * i + 1 for i in range(P)])
