@@ -153,6 +153,8 @@ struct gpc_hip_ctx {
   int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
   int no_partition = 0;       // GPC_HIP_NO_PARTITION: always take the radix-sort path (A/B checks)
   int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
+  int gp_target = 2000;       // GPC_HIP_GP_TARGET: records per side a partition of the non-epipolar matcher aims at. Per 32 pairs of
+                              // 1024x436, join + gather: 1400 -> 208 us, 1800 -> 189, 2000 / 2200 -> 182, 2600 -> 192, 3000 -> 208
   int flat_chunks = 0;        // GPC_HIP_FLAT_CHUNKS: gpc_hip_match_batch with equal chunks only (A/B checks)
   DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
@@ -630,7 +632,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   if (lb > bits) lb = bits;
   L.nbins = 1 << lb;
   L.bshift = bits - lb;
-  L.target = 1400;  // records per side a partition aims at: a third of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
+  L.target = c->gp_target;  // records per side a partition aims at: half of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
   L.cap = GP_NB;
   // cuts happen where a running count <= nmax passes a multiple of the target, and around bins of more than
   // GP_NB - target records (k_gp_plan); the join's grid is what the plan really made (read back with the overflow word)
@@ -1003,6 +1005,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   c->no_partition = getenv("GPC_HIP_NO_PARTITION") != nullptr;
   c->flat_chunks = getenv("GPC_HIP_FLAT_CHUNKS") != nullptr;
+  if (const char* e = getenv("GPC_HIP_GP_TARGET")) {
+    const int v = atoi(e);
+    if (v >= 256 && v <= 3500) c->gp_target = v;
+  }
   if (const char* e = getenv("GPC_HIP_ROWS_PER_CHUNK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) c->rows_per_chunk = v;

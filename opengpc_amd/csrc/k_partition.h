@@ -6,7 +6,7 @@
 //
 // A code must be unique over the whole left image and over the whole right image, and the output is ordered by
 // code.  Instead of sorting all records (four 8-bit radix passes over ~570 k records per pair), the records are
-// PARTITIONED into contiguous code ranges of a few hundred to ~1400 records per side, and every partition goes
+// PARTITIONED into contiguous code ranges of a few hundred to ~2000 records per side, and every partition goes
 // through the same LDS hash join + counting rank as an image row of the epipolar matcher (k_rowjoin.h, VIRT):
 // partitions in ascending order and ranks inside a partition give the reference's output order.
 //   1. k_gp_hist     histogram of the top code bits (256 bins; 512 / 1024 for images beyond ~1 M pixels) per chunk of
