@@ -131,20 +131,26 @@ def cpu_baseline(args, W, H):
     }
 
 
-def compulsory_bytes(W, H, B, M_step):
+def compulsory_bytes(W, H, B, M_step, fused=True):
     """HBM bytes each kernel must move per launch given its input / output formats:
-    what the roofline of that kernel is priced on.  M = supports of the step."""
+    what the roofline of that kernel is priced on.  M = supports of the step.  `fused`: the join writes the 12-byte
+    supports itself (one launch); otherwise it stages 4-byte words and k_gather_rows expands them."""
     rows = H - 26
-    return {
+    d = {
         "k_preprocess": 6.0 * W * H * B,                          # raw read (1 B/px), smooth + grad written, both images
         "k_hash": 12.0 * W * H * B,                               # smooth + grad read, dense 4-byte code image written, both images
-        "k_row_join": 8.0 * W * rows * B + 4.0 * M_step + 4.0 * rows * B,   # both code rows read, packed supports + row counts written
-        "k_gather_rows": 16.0 * M_step + 4.0 * rows * B,          # packed supports read, 12-byte supports written
     }
+    if fused:
+        d["k_row_join"] = 8.0 * W * rows * B + 12.0 * M_step      # both code rows read, 12-byte supports written
+    else:
+        d["k_row_join"] = 8.0 * W * rows * B + 4.0 * M_step + 4.0 * rows * B   # both code rows read, packed supports + row counts written
+        d["k_gather_rows"] = 16.0 * M_step + 4.0 * rows * B       # packed supports read, 12-byte supports written
+    return d
 
 
-BYTES_TEXT = {"k_row_join": "8 B per pixel of the joined rows + 4 B per support", "k_hash": "12 B per pixel",
-              "k_preprocess": "6 B per pixel", "k_gather_rows": "16 B per support"}
+def bytes_text(fused):
+    return {"k_row_join": "8 B per pixel of the joined rows + %d B per support" % (12 if fused else 4), "k_hash": "12 B per pixel",
+            "k_preprocess": "6 B per pixel", "k_gather_rows": "16 B per support"}
 
 
 def main():
@@ -284,7 +290,9 @@ def main():
         # ---- roofline of the dominant kernel: HBM bytes it must move (its formats) / HIP-event time
         N_step = float(ncand.sum())
         M_step = float(counts.sum())
-        alg = compulsory_bytes(W, H, B, M_step)
+        fused = "k_gather_rows" not in ktimes   # the join wrote the supports itself (k_rowjoin.h, FUSE)
+        alg = compulsory_bytes(W, H, B, M_step, fused)
+        BYTES_TEXT = bytes_text(fused)
         kinfo = {}
         for name, (ms, n) in ktimes.items():
             kinfo[name] = {"kernel": launch_names.get(name, name), "avg_us": round(1e3 * ms / n, 2), "launches": n}
@@ -326,7 +334,7 @@ def main():
                     "The kernel keeps the reference's sort in LDS and is bound by LDS / issue, not by HBM: `frac` says how "
                     "far below the HBM roof that leaves it.  `traffic` is not measured by this script; "
                     "`traffic_from_profiles` = 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes.  "
-                    "pipeline_frac = SURVEY 8d's A*pairs/t/peak; pipeline_compulsory_frac = sum of the four kernels' "
+                    "pipeline_frac = SURVEY 8d's A*pairs/t/peak; pipeline_compulsory_frac = sum of the kernels' "
                     "compulsory bytes / step time / peak." % (BYTES_TEXT.get(dom_slot, ""), dom_n),
             "kernels": kinfo,
         }

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -158,6 +159,19 @@ struct gpc_hip_ctx {
   int flat_chunks = 0;        // GPC_HIP_FLAT_CHUNKS: gpc_hip_match_batch with equal chunks only (A/B checks)
   DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
 
+  // fused join + output (k_rowjoin.h, FUSE): ticket counters + look-back granules, launch epoch, error word
+  DevBuf jstate;
+  size_t jstate_granules = 0;
+  uint32_t join_epoch = 0;
+  int32_t* h_err = nullptr;   // page-locked, device-visible: a look-back of the fused join timed out
+  int32_t* d_err = nullptr;   // the device's address of that word
+  int no_fuse = 0;            // GPC_HIP_NO_FUSE: join + k_gather_rows as two launches (A/B checks)
+  int fuse_wgs = 0;           // GPC_HIP_FUSE_WGS: workgroups of the persistent join (tuning; default = what the device holds)
+  int fuse_min_pairs = 1;     // GPC_HIP_FUSE_MIN_PAIRS: smaller batches take the two-launch path
+  int fuse_shards = 16;       // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (tuning)
+  int num_cus = 0;
+  std::map<const void*, int> wgs_per_cu;  // occupancy of the persistent instantiations launched so far
+
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
   int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
@@ -212,7 +226,8 @@ int ensure(gpc_hip_ctx* c, DevBuf& b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
   }
-  size_t want = bytes + bytes / 8 + 256;
+  // slack: growth without reallocation, and the fused join reads whole pixel-slot rows (up to 16 KiB past a row's end)
+  size_t want = bytes + bytes / 8 + 65536;
   HIPCHK(c, hipMalloc(&b.p, want));
   b.cap = want;
   return GPC_OK;
@@ -486,8 +501,39 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
   // S >= NT*SPT because the rank phase reuses the key table as bucket counters
   p.log2s = 1;
   while ((1 << p.log2s) < p.nt * p.spt || ((1 << p.log2s) < 2 * (W - 2 * GPC_R) && p.log2s < 14)) ++p.log2s;
+  // the fused join keeps the matched codes of its rank phase in the upper half of the (then dead) key table: S >= 2 * NT*SPT
+  while (!c->no_fuse && p.spt <= 4 && (1 << p.log2s) < 2 * p.nt * p.spt && p.log2s < 14) ++p.log2s;
   p.lds = ((size_t)8 * ((1u << p.log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
   return p;
+}
+
+// A look-back of the fused join gave up (k_rowjoin.h, RJ_SPIN_LIMIT): the results of that launch are not to be used.
+// Called wherever an entry point has just synchronised the stream.
+int check_join_err(gpc_hip_ctx* c) {
+  if (c->h_err && *c->h_err) {
+    *c->h_err = 0;
+    snprintf(c->err, sizeof(c->err), "k_row_join (fused output): a row waited too long for the rows before it");
+    return GPC_E_HIP;
+  }
+  return GPC_OK;
+}
+
+// State of the fused join: ticket counters + one granule per (pair, row); zeroed when (re)allocated, then kept
+// consistent by the kernel itself (the last draw resets a counter; granules carry the launch's epoch).
+int ensure_join_state(gpc_hip_ctx* c, size_t granules) {
+  const size_t tk_bytes = sizeof(uint32_t) * RJ_SHARDS * RJ_TICKET_STRIDE;
+  if (!c->h_err) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_err, 64, hipHostMallocMapped));
+    *c->h_err = 0;
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0));
+  }
+  if (granules > c->jstate_granules || c->join_epoch >= (1u << 30) - 2u) {
+    CHK(ensure(c, c->jstate, tk_bytes + sizeof(unsigned long long) * granules));
+    HIPCHK(c, hipMemsetAsync(c->jstate.p, 0, c->jstate.cap, c->stream));
+    c->jstate_granules = (c->jstate.cap - tk_bytes) / sizeof(unsigned long long);
+    c->join_epoch = 0;
+  }
+  return GPC_OK;
 }
 
 // code images of npairs pairs -> supports / correspondences in d_out.
@@ -506,6 +552,67 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
     const JoinPlan jp = plan_join(c, W);
     if (jp.nt * jp.spt < W) return GPC_E_UNSUPPORTED;  // unreachable below check_dims' 16384 px
+    // One launch for join + output (k_rowjoin.h, FUSE) where the table leaves room for the ranked words (rows up to
+    // 8192 px) and the records' place follows from the rows before them alone (not the gap-free packing of `totals`)
+    const bool fuse = !c->no_fuse && npairs >= c->fuse_min_pairs && jp.spt <= 4 && (1 << jp.log2s) >= 2 * jp.nt * jp.spt &&
+                      !(po && po->totals) && (long)npairs * (H - 2 * GPC_R) < (1l << 31) - 65536;
+    // keys [S+4 words] | 16-bit flags [S/2 words] | pending row's ranked words [NT*SPT]
+    const size_t flds = (size_t)4 * ((1u << jp.log2s) + 4) + (size_t)2 * (1u << jp.log2s) + (size_t)4 * jp.nt * jp.spt;
+    if (fuse) {
+      const int nrows = H - 2 * GPC_R;
+      CHK(ensure_join_state(c, (size_t)npairs * nrows));
+      gpc::RjFuse f;
+      f.tickets = (uint32_t*)c->jstate.p;
+      f.status = (unsigned long long*)((uint32_t*)c->jstate.p + RJ_SHARDS * RJ_TICKET_STRIDE);
+      f.err = c->d_err;
+      f.epoch = ++c->join_epoch;
+      f.npairs = npairs;
+      f.nshards = npairs < c->fuse_shards ? npairs : c->fuse_shards;
+      f.mode = mode;
+      f.out = d_out;
+      f.cap = cap;
+      f.counts = d_counts;
+      f.ncand = d_ncand;
+      f.rows_out = po ? po->rows : nullptr;
+      f.packed_stride = po ? po->packed_stride : 0l;
+      f.rows_stride = po ? po->rows_stride : 0l;
+      Timed t(c, KID_ROW_JOIN);
+      const bool wide = wide_codes(c);
+      snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join<%d, %d, %s, false, true>", jp.spt, jp.nt,
+               wide ? "true" : "false");
+      c->launch_name[KID_GATHER_ROWS][0] = 0;
+#define LAUNCH_FJOIN(SPT, NT, WIDE)                                                                             \
+  do {                                                                                                          \
+    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, NT, WIDE, false, true>);               \
+    int& per_cu = c->wgs_per_cu[fn_];                                                                           \
+    if (per_cu == 0) {                                                                                          \
+      if (flds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_, NT, flds));                          \
+      if (per_cu < 1) per_cu = 1;                                                                               \
+    }                                                                                                           \
+    long nwg = c->fuse_wgs > 0 ? c->fuse_wgs : (long)per_cu * c->num_cus;                                       \
+    if (nwg > (long)npairs * nrows) nwg = (long)npairs * nrows;                                                 \
+    hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE, false, true>), dim3((unsigned)nwg), dim3(NT), flds, c->stream, \
+                       (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                      \
+                       (const int32_t*)c->stats.p, (uint32_t*)nullptr, (int32_t*)nullptr, jp.log2s, 1,          \
+                       gpc::RjVirt(), f);                                                                       \
+  } while (0)
+#define LAUNCH_FJOIN_W(SPT, NT) do { if (wide) LAUNCH_FJOIN(SPT, NT, true); else LAUNCH_FJOIN(SPT, NT, false); } while (0)
+#define LAUNCH_FJOIN_S(NT)                      \
+  switch (jp.spt) {                             \
+    case 1: LAUNCH_FJOIN_W(1, NT); break;       \
+    case 2: LAUNCH_FJOIN_W(2, NT); break;       \
+    default: LAUNCH_FJOIN_W(4, NT); break;      \
+  }
+      if (jp.nt == 1024) { LAUNCH_FJOIN_S(1024) }
+      else if (jp.nt == 512) { LAUNCH_FJOIN_S(512) }
+      else { LAUNCH_FJOIN_S(256) }
+#undef LAUNCH_FJOIN_S
+#undef LAUNCH_FJOIN_W
+#undef LAUNCH_FJOIN
+      HIPCHK(c, hipGetLastError());
+      return GPC_OK;
+    }
     {
       Timed t(c, KID_ROW_JOIN);
       const int rpw = c->join_rpw > 0 ? c->join_rpw : 1;
@@ -520,7 +627,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
                        (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
                        (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
-                       rpw, gpc::RjVirt());                                                                   \
+                       rpw, gpc::RjVirt(), gpc::RjFuse());                                                    \
   } while (0)
 #define LAUNCH_JOIN_W(SPT, NT) do { if (wide) LAUNCH_JOIN(SPT, NT, true); else LAUNCH_JOIN(SPT, NT, false); } while (0)
 #define LAUNCH_JOIN_S(NT)                      \
@@ -726,7 +833,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
     hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
-                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v);                                             \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v, gpc::RjFuse());                              \
   } while (0)
     if (L.cap > GP_NB) {
       if (wide) LAUNCH_VJOIN(8, true); else LAUNCH_VJOIN(8, false);
@@ -1017,6 +1124,20 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
   if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
+  c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
+  if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 65536) c->fuse_wgs = v;
+  }
+  if (const char* e = getenv("GPC_HIP_FUSE_SHARDS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= RJ_SHARDS) c->fuse_shards = v;
+  }
+  if (const char* e = getenv("GPC_HIP_FUSE_MIN_PAIRS")) {
+    const int v = atoi(e);
+    if (v >= 1) c->fuse_min_pairs = v;
+  }
+  c->num_cus = prop.multiProcessorCount;
   const char* jn = getenv("GPC_HIP_JOIN_NT");
   if (jn && (atoi(jn) == 256 || atoi(jn) == 512 || atoi(jn) == 1024)) c->join_nt = atoi(jn);
   *out = c;
@@ -1030,7 +1151,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed, &c->gpart};
+                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed, &c->gpart, &c->jstate};
   while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -1050,6 +1171,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_cnt) (void)hipHostFree(c->h_cnt);
   if (c->h_flag) (void)hipHostFree(c->h_flag);
+  if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GPC_OK;
@@ -1066,7 +1188,7 @@ int gpc_hip_set_stream(gpc_hip_ctx* c, void* hip_stream) {
 int gpc_hip_synchronize(gpc_hip_ctx* c) {
   if (!c) return GPC_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return GPC_OK;
+  return check_join_err(c);
 }
 
 int gpc_hip_reserve(gpc_hip_ctx* c, int W, int H, int max_pairs) {
@@ -1313,6 +1435,7 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
   int32_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(&cnt, c->counts.p, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  CHK(check_join_err(c));
   *n_out = cnt;
   const int ncopy = cnt < cap ? cnt : cap;
   if (ncopy > 0) HIPCHK(c, hipMemcpy(out, c->out.p, esz * (size_t)ncopy, hipMemcpyDeviceToHost));
@@ -1438,6 +1561,7 @@ static int match_batch_unpacked(gpc_hip_ctx* c, const uint8_t* rawL, const uint8
   HIPCHK(c, hipStreamSynchronize(c->s_out));
   HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  CHK(check_join_err(c));
   return status;
 }
 
@@ -1620,6 +1744,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   c->pool.wait_all();
   HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  CHK(check_join_err(c));
   return status;
 }
 

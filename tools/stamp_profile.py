@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "gpurun_out", "libgpc_hip_stamps.so")
 PHASES = ["loads+init", "insert left", "lookups+adds", "decide", "rank count", "rank scan+scatter", "rank walk+store"]
+FUSED_PHASES = ["loads+init (+ pending row asks)", "insert left", "lookups+adds", "decide (+count)",
+                "rank count (+ pending row's place)", "pending row's records out + scan + scatter", "rank walk"]
 HASH_PHASES = ["wait for other waves", "window arrives + staged + barrier", "next window's loads issued", "candidate flags",
                "tests + transposes", "code stores issued"]
 
@@ -30,18 +32,35 @@ def main():
     s = g.Settings.sparsematch()
     cap = (W - 26) * (H - 26)
     buf = (C.c_ulonglong * 16)()
-    ctx.match_batch(L, R, s, cap)
+    # device-resident launches like bench.py's (the fused join + output runs there; the host entry point packs the
+    # pairs' records gap-free, which takes the two-launch path)
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        return p
+    d_L, d_R = dmalloc(L.nbytes), dmalloc(R.nbytes)
+    d_out, d_cnt, d_nc = dmalloc(B * cap * 12), dmalloc(B * 4), dmalloc(B * 8)
+    assert hip.hipMemcpy(d_L, C.c_void_p(L.ctypes.data), C.c_size_t(L.nbytes), 1) == 0
+    assert hip.hipMemcpy(d_R, C.c_void_p(R.ctypes.data), C.c_size_t(R.nbytes), 1) == 0
+
+    def dev_step():
+        ctx.match_batch_device(d_L.value, d_R.value, W, H, B, s, d_out.value, cap, d_cnt.value, d_nc.value)
+        ctx.synchronize()
+    dev_step()
     ctx.L.gpc_hip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     ctx.L.gpc_hip_debug_stamps(ctx.h, buf)
     for _ in range(3):
-        ctx.match_batch(L, R, s, cap)
+        dev_step()
     ctx.L.gpc_hip_debug_stamps(ctx.h, buf)
-    tot = sum(buf[i] for i in range(len(PHASES)))
-    nblk = 3 * B * len([y for y in range(H - 26) if (y & 63) == 5])
-    print("k_row_join phase shares (s_memtime ticks per workgroup, 100 MHz ticks x clock ratio):")
-    for i, name in enumerate(PHASES):
-        print("  %-14s %6.1f %%   %8.0f ticks/wg" % (name, 100.0 * buf[i] / tot, buf[i] / nblk))
-    print("  total %.0f ticks/wg" % (tot / nblk))
+    fused = os.environ.get("GPC_HIP_NO_FUSE") is None
+    names = FUSED_PHASES if fused else PHASES
+    tot = sum(buf[i] for i in range(len(names)))
+    print("k_row_join (%s) phase shares (s_memtime ticks summed over the sampled workgroups' rows):" % ("fused output" if fused else "two launches"))
+    for i, name in enumerate(names):
+        print("  %-24s %6.1f %%" % (name, 100.0 * buf[i] / tot))
+    print("  total %.0f ticks" % tot)
     HJ = ["bin bounds (scalar loads)", "records arrive", "buckets + counts", "scan", "placed", "10-cap", "ranks",
           "list order + links", "walk + scan", "output"]
     hs = g.Settings(5, 128, 1, True, True, 1)

@@ -6,7 +6,7 @@ mkdir -p "$R/gpurun_out"
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -o /tmp/libgpc_$name.so "$R/opengpc_amd/csrc/gpc_hip.hip" 2>/dev/null || { echo "$name: build failed"; continue; }
-  GPC_HIP_LIB=/tmp/libgpc_$name.so timeout -k 10 200 python "$R/bench.py" --steps 20 --no-cpu-baseline $BENCH_ARGS > "$R/gpurun_out/variant_$name.json" 2> "$R/gpurun_out/variant_$name.err" || { echo "$name: bench failed"; tail -3 "$R/gpurun_out/variant_$name.err"; continue; }
+  GPC_HIP_LIB=/tmp/libgpc_$name.so timeout -k 10 200 python "$R/bench.py" --steps 20 --windows 8 --no-cpu-baseline --no-extras --no-verify $BENCH_ARGS > "$R/gpurun_out/variant_$name.json" 2> "$R/gpurun_out/variant_$name.err" || { echo "$name: bench failed"; tail -3 "$R/gpurun_out/variant_$name.err"; continue; }
   python - "$name" "$R/gpurun_out/variant_$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))
