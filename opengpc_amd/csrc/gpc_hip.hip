@@ -510,6 +510,12 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
 // A look-back of the fused join gave up (k_rowjoin.h, RJ_SPIN_LIMIT): the results of that launch are not to be used.
 // Called wherever an entry point has just synchronised the stream.
 int check_join_err(gpc_hip_ctx* c) {
+#ifdef RJ_DBG_COUNT
+  if (c->h_err && c->h_err[1]) {
+    fprintf(stderr, "[RJ_DBG_COUNT] look-backs %d, first window not ready %d, further polls %d\n", c->h_err[1], c->h_err[2], c->h_err[3]);
+    c->h_err[1] = c->h_err[2] = c->h_err[3] = 0;
+  }
+#endif
   if (c->h_err && *c->h_err) {
     *c->h_err = 0;
     snprintf(c->err, sizeof(c->err), "k_row_join (fused output): a row waited too long for the rows before it");
@@ -524,7 +530,7 @@ int ensure_join_state(gpc_hip_ctx* c, size_t granules) {
   const size_t tk_bytes = sizeof(uint32_t) * RJ_SHARDS * RJ_TICKET_STRIDE;
   if (!c->h_err) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_err, 64, hipHostMallocMapped));
-    *c->h_err = 0;
+    memset(c->h_err, 0, 64);
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0));
   }
   if (granules > c->jstate_granules || c->join_epoch >= (1u << 30) - 2u) {

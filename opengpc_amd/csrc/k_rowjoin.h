@@ -236,6 +236,9 @@ __device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, in
   return 0u;
 #endif
   int pos = t - 1, spin = 0;  // wave-uniform
+#ifdef RJ_DBG_COUNT
+  if (lane == 0) atomicAdd(err + 1, 1);  // [1] look-backs
+#endif
   for (bool first = true;; first = false) {
     if (!first) g = rj_lookback_ask(st - (t - 1 - pos), pos + 1, lane, epoch);
     const uint32_t tag = (uint32_t)(g >> 32);
@@ -245,6 +248,9 @@ __device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, in
     const int first_n = notyet ? __ffsll((long long)notyet) - 1 : 64;
     const int first_p = pfx ? __ffsll((long long)pfx) - 1 : 64;
     if (first_n < first_p) {
+#ifdef RJ_DBG_COUNT
+      if (lane == 0) atomicAdd(err + (first ? 2 : 3), 1);  // [2] first windows not ready, [3] further polls
+#endif
       if (++spin > RJ_SPIN_LIMIT) {
         if (lane == 0) atomicOr(err, 1);
         break;
@@ -279,6 +285,9 @@ __device__ __forceinline__ void rj_emit_row(const RjFuse& f, const uint32_t* __r
 #ifdef RJ_DBG_NOEMIT
   return;
 #endif
+  // (opaque: the per-lane LDS address of words[tid] is loop-invariant, and hoisted out of the row loop it is spilled to
+  // scratch -- whose reload waits for every vector-memory operation of the wave, the ticket draw in flight included)
+  asm volatile("" : "+v"(tid));
   if (f.mode == 0) {
     struct __attribute__((packed, aligned(4))) Rec3 { uint32_t x, y, d; };
     Rec3* o = reinterpret_cast<Rec3*>(f.out) + (long)pair * f.cap;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   // the row whose records are still in D: its pair, row, ticket row, count
   int d_pair = 0, d_y = 0, d_t = -1;
   uint32_t d_cnt = 0u;
-  unsigned long long d_g0 = 0ull;  // first wave: the granules of the pending row's predecessors, asked for during its rank phase
+  unsigned long long d_g0 = 0ull;  // first wave: the granules of the pending row's predecessors
   if (FUSE) {
     f_shard = (int)(blockIdx.x % (unsigned)f.nshards);
     f_ps = (uint32_t)((f.npairs - f_shard + f.nshards - 1) / f.nshards);           // pairs of the shard
@@ -471,6 +480,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     f_t = (int)q;
     y = GPC_R + f_t;
     last_r = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
+    // The pending row asks for its predecessors' granules FIRST: a vector-memory counter is in order, so the answer
+    // is in when this row's codes are, and it is looked at after the insert phase.  (Asked during the pending row's
+    // own walk, 1.8 us after its count went out, a third of the first windows still held a row that had not
+    // published -- rows of a pair run 1.25 us apart on average with more jitter than that -- and each cost a
+    // blocking poll; here the counts are half a row old.)
+    if (d_t >= 0 && tid < 64) d_g0 = rj_lookback_ask(f.status + (long)d_pair * nrows + d_t, d_t, lane, f.epoch);
     fetch_row(y);
   }
   RJ_STAMP_INIT();
@@ -561,9 +576,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(1);
-  // FUSE: the first wave settles the place of the PENDING row here.  Its look-back was asked for during that row's
-  // own walk (a vector-memory counter is in order: the answer is older than this row's code loads, so it has arrived,
-  // and nothing of it stays in registers over the lookup phase); the other waves go on and meet the first at the
+  // FUSE: the first wave settles the place of the PENDING row here.  Its look-back was asked for at the top of this
+  // row, in front of the code loads (a vector-memory counter is in order: the answer has arrived with them, and
+  // nothing of it stays in registers over the lookup phase); the other waves go on and meet the first at the
   // next barrier.  Who does what is spread over the waves because each wave's counter is its own: the first wave
   // asks and publishes, the second draws the tickets -- a wave that did both would wait for the younger of the two
   // whenever it needs the older.
@@ -762,9 +777,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   __syncthreads();
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
-  // FUSE: this row's look-back is asked for now -- its count went out a scan and a scatter ago, and the rows in
-  // front of it, a little ahead in the same phases, have usually published theirs -- and answered in the next row
-  if (FUSE && tid < 64) d_g0 = rj_lookback_ask(f.status + (long)pair * nrows + f_t, f_t, lane, f.epoch);
   // FUSE: the ranked words wait in D for the row's place in the output
   uint32_t* dst = FUSE ? d_words : (VIRT ? v.staged + pair * (v.recs / 2) + v_offl : staged + rowbase * W);
 #pragma unroll
@@ -801,7 +813,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     if (d_t >= 0) {  // the last row of this workgroup is still pending
       if (tid < 64) {
         unsigned long long* d_st = f.status + (long)d_pair * nrows + d_t;
-        const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, d_g0, f.err);
+        const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, rj_lookback_ask(d_st, d_t, lane, f.epoch), f.err);
         if (lane == 0) {
           if (d_t > 0) __hip_atomic_store(d_st, rj_granule(f.epoch, RJ_ST_PREFIX, base + d_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           s_base = base;
