@@ -11,9 +11,9 @@ Pairs shard embarrassingly (pair i -> rank i mod N); the only coll
 the timing barrier / MAX and a gather of per-rank counters.  Prints ONE JSON line on rank 0.
 
 A timed WINDOW is exactly K steps bracketed by barrier + device sync on both sides (the driver's
-contract).  K steps last ~30 ms, too short to be seen from outside, so the window is repeated
-(--windows, default 35 => the GPU is busy for > 1 s) and the MEDIAN window is reported; min / max
-are in the line.  The reference's own timed region is host-to-host: `pcie_inclusive` measures that
+contract).  K = 20 steps last ~23 ms, too short to be seen from outside, so the window is repeated
+(--windows, default 260 => the timed windows keep the GPU busy for ~6 s) and the MEDIAN window is
+reported; min / max are in the line.  The reference's own timed region is host-to-host: `pcie_inclusive` measures that
 in the same run and `speedup_vs_cpu_1thread` compares like with like.
 """
 import argparse
@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=35,
+    ap.add_argument("--windows", type=int, default=260,
                     help="timed windows of --steps steps each (every one bracketed by barrier + sync); the median is reported")
     ap.add_argument("--batch", type=int, default=256,
                     help="pairs per GPU per step: BASELINE configs[3]'s batch of 256 pairs, one such batch per GPU")
@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the single-pair, two-stream and PCIe-inclusive side measurements (profiling runs: every "
                          "launch of a kernel then has the same grid, so rocprofv3's averages match the HIP-event ones)")
+    ap.add_argument("--host-path", action="store_true",
+                    help="measure the host-to-host call on every rank even with --no-extras (rehearsals of the N > 1 line)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (HIP streams + workspaces) the steps alternate over; 1 = strictly serial steps")
     return ap.parse_args()
@@ -273,13 +275,50 @@ def main():
         if not verified:
             print("bench.py: rank %d: GPU supports differ from the oracle" % rank, file=sys.stderr)
 
+    # ---- the reference's own timed region on EVERY rank at once: raw pairs in page-locked host memory -> gpc_support
+    #      arrays in host memory, one synchronous gpc_hip_match_batch call per rank and repetition, barrier-bracketed
+    #      (the ranks of a node share the host's memory bandwidth and CPUs, so they are timed together); the slowest
+    #      rank of a repetition counts.  At one rank this is `pcie_inclusive.in_this_process`.
+    host_reps, host_times, host_ok, host_threads = 9, [], True, 0
+    if not args.no_extras or args.host_path:
+        capi_cap = 300000
+        Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
+        Lp[:] = Lh
+        Rp[:] = Rh
+        outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
+        res = {}
+
+        def host_call():
+            res["r"] = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
+        for _ in range(3):
+            host_call()
+        host_times = gdist.timed_calls(host_call, host_reps)
+        o_, c_, n_, st_ = res["r"]
+        host_ok = bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts))
+        host_threads = int(ctx.L.gpc_hip_host_threads(ctx.h))
+        del Lp, Rp, outb
+
     # O(100 B) per rank over xGMI: timing / counters only, never pixel data
     row = [float(B), float(ncand.sum()), float(counts.sum()), 1.0 if verified in (True, None) else 0.0,
-           float(n_verified)] + [float(t) for t in windows]
+           float(n_verified), 1.0 if host_ok else 0.0, float(host_threads)] + [float(t) for t in host_times] + \
+          [float(t) for t in windows]
     allr = gdist.gather_stats(row, device=dev).numpy()
     if float(allr[:, 3].min()) < 1.0:
         raise SystemExit("bench.py: GPU supports differ from the oracle on some rank -- refusing to report a number")
-    win = np.sort(allr[:, 5:].max(axis=0))          # per window: the slowest rank
+    nh = len(host_times)
+    win = np.sort(allr[:, 7 + nh:].max(axis=0))     # per window: the slowest rank
+    host_all = None
+    if nh:
+        hs = np.sort(allr[:, 7:7 + nh].max(axis=0))  # per repetition: the slowest rank
+        th = float(hs[len(hs) // 2])
+        host_all = {"ms_per_call": round(th * 1e3, 3), "value": round(2.0 * W * H * float(allr[:, 0].sum()) / th / 1e6, 1),
+                    "unit": "Mpix/s", "pairs_per_call_per_rank": B, "ranks": int(world),
+                    "ms_per_call_min": round(float(hs[0]) * 1e3, 3), "ms_per_call_max": round(float(hs[-1]) * 1e3, 3),
+                    "identical_to_device_path": bool(float(allr[:, 5].min()) >= 1.0),
+                    "expand_threads_per_rank": int(allr[:, 6].min()),
+                    "note": "every rank's synchronous gpc_hip_match_batch call at the same moment (barrier before each "
+                            "repetition), all pairs of all ranks / the slowest rank's time, median of %d repetitions after 3 "
+                            "untimed; from this process, whose HIP runtime is the one bundled with torch" % nh}
     t_med = float(win[len(win) // 2])
     pairs_per_step = float(allr[:, 0].sum())
 
@@ -362,7 +401,7 @@ def main():
         #      imported torch runs every HIP library on the ROCm runtime bundled with the torch wheel (an older one
         #      than the /opt/rocm this library is built against; its copies are slower).  So the call is timed in a
         #      child process without torch -- the C++ caller's situation -- and, for the record, in this process too.
-        pcie = None
+        pcie, single_h2h = None, None
         if world == 1 and not args.no_extras:
             import subprocess
             import zlib
@@ -376,32 +415,20 @@ def main():
                 for j in (0, B // 2, B - 1):   # the device path's 12-byte records of three pairs, byte for byte
                     same = same and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
                 pcie["identical_to_device_path"] = same
+                single_h2h = pcie.pop("single_pair_host_to_host", None)
                 pcie["measured_in"] = "child process without torch (the library's own ROCm runtime)"
                 pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 15 calls after 5 untimed"
             except Exception as e:  # the headline does not depend on it
                 pcie = None
                 print("bench.py: pcie_inclusive child failed: %r" % (e,), file=sys.stderr)
-            # the same call inside this (torch) process
-            capi_cap = 300000
-            Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
-            Lp[:] = Lh
-            Rp[:] = Rh
-            outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
-            for _ in range(3):
-                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
-            tt = []
-            for _ in range(9):
-                t0 = time.perf_counter()
-                o_, c_, n_, st_ = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
-                tt.append(time.perf_counter() - t0)
-            tt.sort()
-            here = {"ms_per_call": round(tt[len(tt) // 2] * 1e3, 3), "value": round(2.0 * W * H * B / tt[len(tt) // 2] / 1e6, 1),
-                    "identical_to_device_path": bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts)),
-                    "note": "same call from this process, whose HIP runtime is the one bundled with torch"}
+            # the same call inside this (torch) process: measured on every rank above
             if pcie is None:
-                pcie = dict(here, unit="Mpix/s", pairs_per_call=B, measured_in="this process (torch's bundled ROCm runtime)")
-            else:
-                pcie["in_this_process"] = here
+                pcie = dict(host_all, measured_in="this process (torch's bundled ROCm runtime)") if host_all else None
+            elif host_all:
+                pcie["in_this_process"] = host_all
+        elif host_all:   # world > 1: all ranks at once (no torch-free child per rank)
+            pcie = dict(host_all, measured_in="the bench processes themselves, all ranks at once",
+                        timed_region="host images -> host gpc_support arrays (sparsematch.cpp:45-52)")
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -493,6 +520,8 @@ def main():
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
             "single_pair": single,
+            "single_pair_host_to_host": single_h2h,
+            "host_to_host_all_ranks": host_all,
             "two_stream_pipeline": two,
         }
         if cpu:

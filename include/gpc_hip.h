@@ -153,7 +153,17 @@ int gpc_hip_match_pair(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* raw
 /* ---- device-resident batch entry points ------------------------------------- */
 /* `npairs` raw pairs already in HBM ([npairs][height][width] each side) -> supports in
  * HBM: d_out[npairs][cap_per_pair], d_counts[npairs] (true counts), and, if non-NULL,
- * d_ncand[npairs][2] candidate counts.  Asynchronous on the context's stream. */
+ * d_ncand[npairs][2] candidate counts.
+ * With the reference's sparsematch settings (epipolar_mode = 1, use_hashtable = 0) the call is
+ * ASYNCHRONOUS on the context's stream: three launches are queued and it returns.
+ * With epipolar_mode = 0 or use_hashtable = 1 (the device-wide matchers) it SYNCHRONISES the stream
+ * once or twice inside the call: those matchers partition the records by code / bucket range and read
+ * one word back to learn whether every partition fits a workgroup (if not -- heavily repeated codes --
+ * the whole batch takes the radix-sort path instead).  In either case the outputs may be read only
+ * after gpc_hip_synchronize (or another wait on the stream).
+ * The join that writes the supports places a row behind the rows before it with a bounded wait on
+ * other workgroups; a wait that ran out (not observed so far) is reported by the next
+ * gpc_hip_synchronize as GPC_E_HIP and the outputs of that launch must not be used. */
 int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const uint8_t* d_rawR,
                                int width, int height, int npairs, const gpc_settings* settings,
                                gpc_support* d_out, int cap_per_pair, int32_t* d_counts,
@@ -166,6 +176,11 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const ui
 int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
                         int width, int height, int npairs, const gpc_settings* settings,
                         gpc_support* out, int cap_per_pair, int32_t* counts, int32_t* ncand);
+
+/* Host threads gpc_hip_match_batch last used to expand packed results (0 before the first such call).  Default:
+ * settings->num_threads if > 1, else the CPUs this process may use -- divided by LOCAL_WORLD_SIZE when a launcher
+ * starts one process per GPU -- less the feeding thread, between 2 and 8. */
+int gpc_hip_host_threads(const gpc_hip_ctx* ctx);
 
 /* ---- packed results ------------------------------------------------------------ */
 /* Forest::rectifiedMatch (inference.hpp:375-393) in epipolar mode emits supports row by row, so a support

@@ -5,7 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
-#include <emmintrin.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>   // the host expansion of packed results has an SSE2 path (x86 hosts); scalar otherwise
+#endif
 #include <sched.h>
 
 #include <cctype>
@@ -137,6 +139,8 @@ struct gpc_hip_ctx {
   int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
   size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
+  int direct_max = 2;             // GPC_HIP_DIRECT_MAX: batches up to this size with a page-locked `out` are written by the
+                                  // kernels straight into the caller's array (no packed records, no host expansion); 0 = never
   int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
   int expand_threads = 0;         // GPC_HIP_EXPAND_THREADS (tuning)
   char err[256] = {0};
@@ -146,6 +150,7 @@ struct gpc_hip_ctx {
   GpcForestDev forest;        // tests in file order (SSE bit placement)
   GpcForestDev forest_naive;  // tests reversed: slot u = test T-1-u lands on bit u (MSB-first codes), raw int tau
   int forest_w = 0, forest_h = 0;
+  gpc_filter_mask forest_src;  // what gpc_hip_set_forest was last given: the same forest again costs nothing
 
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
@@ -287,7 +292,36 @@ int usable_cpus() {
     }
     fclose(fp);
   }
+  if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long quota = -1, per = 0;
+    if (fscanf(fp, "%ld", &quota) == 1 && quota > 0) {
+      if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(fq, "%ld", &per) == 1 && per > 0 && quota / per >= 1 && quota / per < n) n = (int)(quota / per);
+        fclose(fq);
+      }
+    }
+    fclose(fp);
+  }
   return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+// Worker threads gpc_hip_match_batch may start for the host expansion when nobody said how many: the process's CPUs
+// shared among the ranks of this node (one process per GPU sets LOCAL_WORLD_SIZE, torch.distributed.run does), less one
+// for the thread that feeds the GPU; at least 2, at most 8 (3 .. 10 workers all keep up with the link).
+int default_expand_threads() {
+  int share = 0;
+  int local_world = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) local_world = v;
+  }
+  cpu_set_t set;
+  int visible = 1;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) visible = CPU_COUNT(&set);
+  // a one-GPU box gives the process a quota of its own (usable_cpus sees it); on a node shared by the ranks of one
+  // job every rank sees all CPUs and must share them
+  share = local_world > 1 ? visible / local_world - 1 : usable_cpus() - 2;
+  return share < 2 ? 2 : (share > 8 ? 8 : share);
 }
 
 // Packed supports (xL | xR << 16, rows in ascending order, rows[y] of them in row y) -> ndb::Support records
@@ -297,8 +331,10 @@ int usable_cpus() {
 void expand_rows(const uint32_t* packed, const int32_t* rows, int y0, int y1, long first, long limit, gpc_support* out) {
   long pos = first;
   const uint32_t* src = packed + first;
+#if defined(__SSE2__)
   const bool aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
   const __m128i m16 = _mm_set1_epi32(0xFFFF);
+#endif
   for (int y = y0; y < y1 && pos < limit; ++y) {
     const long cnt = rows[y];
     long n = cnt;
@@ -311,6 +347,7 @@ void expand_rows(const uint32_t* packed, const int32_t* rows, int y0, int y1, lo
       out[pos].d = (float)(xl - xr);
       ++pos;
     };
+#if defined(__SSE2__)
     if (aligned) {
       for (; i < n && (pos & 3); ++i) one(src[i]);
       const __m128 Y = _mm_castsi128_ps(_mm_set1_epi32(y));
@@ -331,10 +368,13 @@ void expand_rows(const uint32_t* packed, const int32_t* rows, int y0, int y1, lo
         _mm_stream_si128(o + 2, _mm_castps_si128(c));
       }
     }
+#endif
     for (; i < n; ++i) one(src[i]);
     src += cnt;
   }
+#if defined(__SSE2__)
   _mm_sfence();
+#endif
 }
 
 void ExpandPool::run() {
@@ -737,7 +777,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   *done = false;
   const bool wide = wide_codes(c);
   const int bits = wide ? 32 : code_bits(c);
-  gpc::GpLayout L;
+  gpc::GpLayout L = {};
   // 256 bins (8 top code bits) up to ~1 M record slots per pair; 512 / 1024 for larger images, so that a bin of a textured
   // image still holds about a partition's worth of records (the scatter's runs get shorter: k_partition.h)
   int lb = 8;
@@ -750,6 +790,10 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   // cuts happen where a running count <= nmax passes a multiple of the target, and around bins of more than
   // GP_NB - target records (k_gp_plan); the join's grid is what the plan really made (read back with the overflow word)
   L.pmax = g.nmax / L.target + 2 * (g.nmax / (GP_NB - L.target)) + 2;
+  // ... and a partition is a run of whole bins, so there are never more partitions than bins: without this bound the
+  // plan kernel's LDS (8 bytes per possible partition) outgrew a workgroup's 160 KiB from ~6.5 M pixels on and the
+  // launch failed where the radix path would have served (3840x2160: 189 KB)
+  if (L.pmax > L.nbins) L.pmax = L.nbins;
   const int rows = H - 2 * GPC_R;
   L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;  // >= 4 chunks per image
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
@@ -1126,6 +1170,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) c->rows_per_chunk = v;
   }
+  if (const char* e = getenv("GPC_HIP_DIRECT_MAX")) {
+    const int v = atoi(e);
+    if (v >= 0 && v <= 4096) c->direct_max = v;
+  }
   const char* ck = getenv("GPC_HIP_CHUNK");
   if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
@@ -1287,6 +1335,13 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
   if (!c || !fm) return GPC_E_INVALID;
   if (fm->num_tests < 0 || fm->num_tests > GPC_MAX_TESTS) return GPC_E_INVALID;
   CHK(check_dims(fm->width, fm->height));
+  // The header-only C++ API is stateless like the reference's Forest and hands the forest over with every match call:
+  // the same tests again must not cost a stream synchronisation and a blocking copy (~30 us of a 0.2 ms call)
+  if (c->have_forest && fm->num_tests == c->forest_src.num_tests && fm->type == c->forest_src.type &&
+      fm->width == c->forest_src.width && fm->height == c->forest_src.height &&
+      memcmp(fm->mask, c->forest_src.mask, sizeof(int32_t) * 2 * (size_t)fm->num_tests) == 0 &&
+      memcmp(fm->tau, c->forest_src.tau, sizeof(int32_t) * (size_t)fm->num_tests) == 0)
+    return GPC_OK;
   const int W = fm->width;
   GpcForestDev f, fn;
   memset(&f, 0, sizeof f);
@@ -1326,6 +1381,7 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
   HIPCHK(c, hipMemcpy(c->forest_dev.p, both, sizeof both, hipMemcpyHostToDevice));
   c->forest_w = fm->width;
   c->forest_h = fm->height;
+  c->forest_src = *fm;
   c->have_forest = true;
   return GPC_OK;
 }
@@ -1601,8 +1657,74 @@ int gpc_hip_expand_packed(const uint32_t* packed, const int32_t* rows, int H, in
 // expand them into the caller's ndb::Support arrays while the next chunks are uploaded, matched and downloaded.
 // Per chunk k:  upload (s_in) -> kernels (stream) -> counts (s_cnt) | download of k-1 (s_out) | expansion of k-2 (pool).
 // Device results rotate through 3 slots, the page-locked landing area through 4.
+static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand);
+
+// The device's address of page-locked host memory the GPU can write (hipHostMalloc / gpc_hip_host_alloc), or null.
+static void* device_view_of_host(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error of this library
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+  return a.devicePointer;
+}
+
+// One pair or two, page-locked `out` (BASELINE configs[1] taken literally: the reference's timed region for ONE pair).
+// The chunk pipeline of match_batch_packed is built for the link's throughput: three streams, events, packed records
+// and a pool of host threads that expand them -- for one pair that machinery IS the latency (0.20-0.24 ms against
+// ~36 us of kernels and ~35 us of link time).  Here everything is queued on the context's stream and the join writes
+// the 12-byte supports, the counts and the candidate counts straight into host memory over the link (consecutive
+// lanes write consecutive records: whole PCIe write bursts) while it runs; one stream synchronisation ends the call.
+static int match_batch_direct(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                              const gpc_settings* s, gpc_support* d_out_host, int cap, int32_t* counts, int32_t* ncand) {
+  const size_t n = (size_t)W * H;
+  CHK(ensure(c, c->raw, 2 * n * npairs));
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
+  CHK(pinned_counts(c, npairs));
+  int32_t* d_cnt = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer((void**)&d_cnt, c->h_cnt, 0));
+  uint8_t* d_l = (uint8_t*)c->raw.p;
+  uint8_t* d_r = d_l + n * npairs;
+  HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
+  CHK(run_preprocess(c, d_l, d_r, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false, (uint32_t*)c->codes.p));
+  CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out_host, cap, d_cnt, d_cnt + npairs));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  CHK(check_join_err(c));
+  int status = GPC_OK;
+  for (int p = 0; p < npairs; ++p) {
+    counts[p] = c->h_cnt[p];
+    if (counts[p] > cap) status = GPC_E_CAPACITY;
+    if (ncand) {
+      ncand[2 * p] = c->h_cnt[npairs + 2 * p];
+      ncand[2 * p + 1] = c->h_cnt[npairs + 2 * p + 1];
+    }
+  }
+  return status;
+}
+
 int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
                         const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
+  const int st = match_batch_packed(c, rawL, rawR, W, H, npairs, s, out, cap, counts, ncand);
+  if (c && st != GPC_OK && st != GPC_E_CAPACITY && st != GPC_E_INVALID) {
+    // An error left the chunk pipeline half way: expansion jobs may still write into `out`, copies may still
+    // target the staging slots.  Nothing of this call may be in flight when the caller gets its buffers back.
+    c->pool.wait_all();
+    if (c->s_in) {
+      (void)hipStreamSynchronize(c->s_in);
+      (void)hipStreamSynchronize(c->s_out);
+      (void)hipStreamSynchronize(c->s_cnt);
+    }
+    (void)hipStreamSynchronize(c->stream);
+  }
+  return st;
+}
+
+static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
   if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
   CHK(check_settings(s));
   if (!s->epipolar_mode || s->use_hashtable)
@@ -1610,6 +1732,9 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   CHK(check_dims(W, H));
   CHK(forest_matches(c, W, H));
   HIPCHK(c, hipSetDevice(c->device));
+  if (npairs <= c->direct_max && (uint64_t)cap * sizeof(gpc_support) < (1ull << 32))
+    if (void* dv = device_view_of_host(out))
+      return match_batch_direct(c, rawL, rawR, W, H, npairs, s, (gpc_support*)dv, cap, counts, ncand);
   const size_t n = (size_t)W * H;
   int chunk = npairs < 4 ? npairs : (npairs / 8 < 1 ? 1 : (npairs / 8 > 16 ? 16 : npairs / 8));
   if (c->chunk_pairs > 0) chunk = c->chunk_pairs < npairs ? c->chunk_pairs : npairs;
@@ -1670,8 +1795,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   {  // numThreads_ of the reference's settings asks for that many workers; otherwise what the process may use
     // (measured, 256 pairs: 3 .. 10 workers all keep up with the link -- 8.7 .. 8.9 ms per call, the link's 57 GB/s
     // shared by both directions being the limit; 14 workers on a 16-CPU share: 10.9 ms)
-    int nt = c->expand_threads > 0 ? c->expand_threads : (s->num_threads > 1 ? s->num_threads : usable_cpus() - 2);
-    if (c->expand_threads <= 0 && s->num_threads <= 1 && nt > 8) nt = 8;
+    int nt = c->expand_threads > 0 ? c->expand_threads : (s->num_threads > 1 ? s->num_threads : default_expand_threads());
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
     c->pool.start(nt);
   }
@@ -1753,6 +1877,8 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
   CHK(check_join_err(c));
   return status;
 }
+
+int gpc_hip_host_threads(const gpc_hip_ctx* c) { return c ? c->pool.size() : 0; }
 
 int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H,
                        const gpc_settings* s, gpc_support* out, int cap, int* n_out, int* n_cand_l,

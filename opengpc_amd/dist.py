@@ -56,6 +56,19 @@ def timed_steps(step, steps, device_sync):
     return time.perf_counter() - t0
 
 
+def timed_calls(call, reps):
+    """Times `reps` synchronous host calls, every one bracketed by a barrier, so that the ranks of a node run theirs
+    at the same moment (they share the host's memory bandwidth and CPUs).  Returns this rank's seconds per call."""
+    out = []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        call()
+        out.append(time.perf_counter() - t0)
+    barrier()
+    return out
+
+
 def gather_stats(values, device="cpu"):
     """all_gather of a short list of floats; returns a [world][len(values)] float64 tensor on the CPU."""
     local = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)

@@ -407,3 +407,24 @@ def test_large_images_in_the_device_wide_modes(ctx, forest_paths):
             got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, ht, 1))
             assert st == 0 and (nl, nr) == ncand and n == len(want) and n > 100000
             assert np.array_equal(got, want.astype(got.dtype))
+
+
+def test_4k_pair_in_the_device_wide_modes(ctx, forest_paths):
+    """3840x2160 (BASELINE configs[4]'s size) with epipolarMode off and with the hash table: beyond ~6.5 M pixels the
+    partition plan used to ask for more LDS than a workgroup has (8 bytes per POSSIBLE partition) and the call failed
+    with a HIP error although the radix path serves such images.  The plan is bounded by its bin count now; whichever
+    path runs, the supports are the oracle's."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    from oracle.pyoracle import Oracle
+    fast = Oracle(fast=True)
+    W, H = 3840, 2160
+    L, R = synth_pair(W, H, 2, 64)
+    rc, f = fast.read_forest(forest_paths["zero"], W, H)
+    ctx.load_forest(forest_paths["zero"], W, H)
+    for epi, ht in ((False, False), (False, True)):
+        want, nl, nr = fast.match_pair(L, R, f, sparsematch_settings(5, 128, 1, epi, ht))
+        got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, ht, 1))
+        # (the reference's 214673-bucket table is far over-full at this size: 10 records per bucket kept of ~53)
+        assert st == 0 and (nl, nr) == ncand and n == len(want) and n > (100 if ht else 100000)
+        assert np.array_equal(got, want.astype(got.dtype))

@@ -111,10 +111,15 @@ def test_rccl_path_rehearsal_on_one_gpu(tmp_path):
     env = dict(os.environ, GPC_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--windows", "3", "--batch", "16", "--verify-pairs", "3", "--no-cpu-baseline", "--no-extras"],
+                          "--windows", "3", "--batch", "16", "--verify-pairs", "3", "--no-cpu-baseline", "--no-extras",
+                          "--host-path"],
                          env=env, check=True, capture_output=True, text=True, timeout=600).stdout
     line = json.loads(out.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["windows"]["count"] == 3
     assert line["verified_vs_oracle"] is True and line["verified_pairs"] == 3
     assert line["value"] > 1000 and line["config"]["parallelism"] == "pairs-dp1"
     assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["kernel"].startswith("gpc::k_")
+    # the reference's host-to-host region, timed on every rank at once between RCCL barriers (what a SCALE line carries)
+    hh = line["host_to_host_all_ranks"]
+    assert hh["ranks"] == 1 and hh["pairs_per_call_per_rank"] == 16 and hh["value"] > 100 and hh["identical_to_device_path"] is True
+    assert 1 <= hh["expand_threads_per_rank"] <= 32

@@ -43,8 +43,56 @@ def one(B, W, H, forest):
            "bytes_in": int(L.nbytes + R.nbytes), "bytes_over_the_link_out": int(counts.sum()) * 4 + B * H * 4,
            "bytes_delivered": int(counts.sum()) * 12, "counts": [int(v) for v in counts],
            "crc32": {str(j): zlib.crc32(o[j, : int(counts[j])].tobytes()) for j in (0, B // 2, B - 1)}}
+    rec["single_pair_host_to_host"] = single_pair(ctx, W, H, s)
+    rec["host"] = host_info(ctx)
     print(json.dumps(rec))
     ctx.close()
+
+
+def host_info(ctx):
+    """What the host side of the call had to work with (the expansion of packed records is CPU work)."""
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    info = {"cpu_model": model, "cpus_visible": len(os.sched_getaffinity(0)), "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
+    try:
+        info["expand_threads"] = int(ctx.L.gpc_hip_host_threads(ctx.h))
+    except Exception:
+        pass
+    return info
+
+
+def single_pair(ctx, W, H, s):
+    """BASELINE configs[1] taken literally: ONE pair, host images -> host supports (the reference's t0..t2), page-locked
+    and pageable buffers; first call and median of 50."""
+    L, R = synth_batch(W, H, [0])
+    cap = 300000
+    res = {}
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            Lb, Rb = ctx.pinned_empty(L.shape, np.uint8), ctx.pinned_empty(R.shape, np.uint8)
+            Lb[:] = L
+            Rb[:] = R
+            out = ctx.pinned_empty((1, cap), g.SUPPORT_DTYPE)
+        else:
+            Lb, Rb, out = L.copy(), R.copy(), np.empty((1, cap), g.SUPPORT_DTYPE)
+        tt = []
+        for _ in range(60):
+            t0 = time.perf_counter()
+            o, counts, ncand, st = ctx.match_batch(Lb, Rb, s, cap, out=out)
+            tt.append(time.perf_counter() - t0)
+        first, rest = tt[0], sorted(tt[10:])
+        res[kind] = {"ms_first_call": round(first * 1e3, 4), "ms_median": round(rest[len(rest) // 2] * 1e3, 4),
+                     "ms_min": round(rest[0] * 1e3, 4), "Mpix_per_s": round(2.0 * W * H / rest[len(rest) // 2] / 1e6, 1),
+                     "supports": int(counts[0]), "status": int(st)}
+    res["timed_region"] = "one synchronous gpc_hip_match_batch call with one pair: host images -> host gpc_support array (sparsematch.cpp:45-52)"
+    return res
 
 
 def main():
