@@ -114,6 +114,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Ends with a barrier.
 template <int SPT, int NT = 256>
 __device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_t* __restrict__ s_w, int tid) {
+  // (opaque: inside a row loop the addresses derived from tid are loop-invariant; hoisted at 64 VGPRs they are spilled to
+  // scratch, and a scratch reload waits for every vector-memory operation the wave has in flight)
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = tid >> 6;
   uint32_t v[SPT];
   uint32_t sum = 0;

@@ -228,42 +228,57 @@ __device__ __forceinline__ unsigned long long rj_lookback_ask(const unsigned lon
 
 // Supports of the pair's rows before row t (one whole wave; every lane gets the result).  g = rj_lookback_ask's answer.
 // Counts are added up to the nearest published prefix; a window in which a row in front of that prefix has not
-// published yet is asked for again (bounded: then *err is set and the sum so far returned).
+// published yet is asked for again (bounded: then *err is set and the sum so far returned).  Beyond the first window
+// -- few pairs in flight: hundreds of rows of one pair run together and the nearest prefix is that far back --
+// RJ_LB_WINDOWS windows are asked for at a time, so that a round trip covers 256 rows.
+#define RJ_LB_WINDOWS 4
 __device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, int t, int lane, uint32_t epoch,
                                                 unsigned long long g, int32_t* err) {
   uint32_t base = 0u;
 #ifdef RJ_DBG_NOLB
   return 0u;
 #endif
-  int pos = t - 1, spin = 0;  // wave-uniform
+  int pos = t - 1, spin = 0;  // wave-uniform: the row lane 0 of the next window looks at
 #ifdef RJ_DBG_COUNT
   if (lane == 0) atomicAdd(err + 1, 1);  // [1] look-backs
 #endif
-  for (bool first = true;; first = false) {
-    if (!first) g = rj_lookback_ask(st - (t - 1 - pos), pos + 1, lane, epoch);
-    const uint32_t tag = (uint32_t)(g >> 32);
+  // one window: adds what it can; returns 1 when the prefix was reached, 0 when the window was all counts, -1 when a
+  // row in front of the nearest prefix has not published yet
+  auto window = [&](unsigned long long gv) -> int {
+    const uint32_t tag = (uint32_t)(gv >> 32);
     const bool ready = (tag >> 2) == epoch;
     const unsigned long long notyet = __ballot(!ready);
     const unsigned long long pfx = __ballot(ready && (tag & 3u) == RJ_ST_PREFIX);
     const int first_n = notyet ? __ffsll((long long)notyet) - 1 : 64;
     const int first_p = pfx ? __ffsll((long long)pfx) - 1 : 64;
-    if (first_n < first_p) {
+    if (first_n < first_p) return -1;
+    uint32_t c = (lane <= first_p) ? (uint32_t)gv : 0u;  // counts of the rows in front of the prefix, and the prefix
+    c = wave_incl_scan(c);
+    base += (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+    return first_p < 64 ? 1 : 0;
+  };
+  int r = window(g);
+  if (r == 0) pos -= 64;
+  while (r != 1) {
+    if (r < 0) {
 #ifdef RJ_DBG_COUNT
-      if (lane == 0) atomicAdd(err + (first ? 2 : 3), 1);  // [2] first windows not ready, [3] further polls
+      if (lane == 0) atomicAdd(err + 2, 1);  // [2] windows with a row that had not published
 #endif
       if (++spin > RJ_SPIN_LIMIT) {
         if (lane == 0) atomicOr(err, 1);
         break;
       }
       __builtin_amdgcn_s_sleep(2);
-      continue;
     }
-    uint32_t c = (lane <= first_p) ? (uint32_t)g : 0u;  // counts of the rows in front of the prefix, and the prefix
-    c = wave_incl_scan(c);
-    base += (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
-    if (first_p < 64) break;
-    pos -= 64;
-    spin = 0;
+    unsigned long long gw[RJ_LB_WINDOWS];
+#pragma unroll
+    for (int k = 0; k < RJ_LB_WINDOWS; ++k) gw[k] = rj_lookback_ask(st - (t - 1 - (pos - 64 * k)), pos - 64 * k + 1, lane, epoch);
+#pragma unroll
+    for (int k = 0; k < RJ_LB_WINDOWS; ++k) {
+      r = window(gw[k]);
+      if (r != 0) break;  // done, or a row of this window has to be waited for
+      pos -= 64;
+    }
   }
   return base;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs a few batched steps of the hot path without torch (fast start-up) -- the target of
-rocprofv3 kernel-trace / PMC runs.  Usage: python3 tools/prof_step.py [steps] [batch] [W] [H] [forest]"""
+rocprofv3 kernel-trace / PMC runs.  Usage: python3 tools/prof_step.py [steps] [batch] [W] [H] [forest] [s D]"""
 import os
 import sys
 
@@ -22,7 +22,13 @@ def main():
     epipolar = os.environ.get("GPC_PROF_GLOBAL") is None
     ctx = g.Context(0)
     ctx.load_forest(forest, W, H)
-    L, R = synth_batch(W, H, list(range(B)))
+    if len(sys.argv) > 7:   # BASELINE configurations with their own (s, D): pair i uses s + i, D
+        from opengpc_amd.synth import synth_pair
+        s0, D = int(sys.argv[6]), int(sys.argv[7])
+        prs = [synth_pair(W, H, s0 + i, D) for i in range(B)]
+        L, R = np.stack([p[0] for p in prs]), np.stack([p[1] for p in prs])
+    else:
+        L, R = synth_batch(W, H, list(range(B)))
     s = g.Settings.sparsematch()
     s.epipolar_mode = int(epipolar)
     s.use_hashtable = int(os.environ.get("GPC_PROF_HASHTABLE") is not None)
