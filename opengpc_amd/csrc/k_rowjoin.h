@@ -495,12 +495,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     f_t = (int)q;
     y = GPC_R + f_t;
     last_r = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
-    // The pending row asks for its predecessors' granules FIRST: a vector-memory counter is in order, so the answer
-    // is in when this row's codes are, and it is looked at after the insert phase.  (Asked during the pending row's
-    // own walk, 1.8 us after its count went out, a third of the first windows still held a row that had not
-    // published -- rows of a pair run 1.25 us apart on average with more jitter than that -- and each cost a
-    // blocking poll; here the counts are half a row old.)
-    if (d_t >= 0 && tid < 64) d_g0 = rj_lookback_ask(f.status + (long)d_pair * nrows + d_t, d_t, lane, f.epoch);
     fetch_row(y);
   }
   RJ_STAMP_INIT();
@@ -591,22 +585,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(1);
-  // FUSE: the first wave settles the place of the PENDING row here.  Its look-back was asked for at the top of this
-  // row, in front of the code loads (a vector-memory counter is in order: the answer has arrived with them, and
-  // nothing of it stays in registers over the lookup phase); the other waves go on and meet the first at the
-  // next barrier.  Who does what is spread over the waves because each wave's counter is its own: the first wave
-  // asks and publishes, the second draws the tickets -- a wave that did both would wait for the younger of the two
-  // whenever it needs the older.
-  if (FUSE) {
-    if (d_t >= 0 && tid < 64) {
-      unsigned long long* d_st = f.status + (long)d_pair * nrows + d_t;
-      const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, d_g0, f.err);
-      if (lane == 0) {
-        if (d_t > 0) __hip_atomic_store(d_st, rj_granule(f.epoch, RJ_ST_PREFIX, base + d_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base = base;
-      }
-    }
-  }
+  // FUSE: the first wave asks for the granules of the PENDING row's predecessors here and looks at the answer after
+  // the lookup phase (the wave has no other vector-memory operation in flight then: its counter is in order, and a
+  // wait for an older load would wait for this one too).  Who does what is spread over the waves for the same reason:
+  // the first wave asks and publishes, the second draws the tickets.  When to ask was measured (256 pairs, first
+  // windows that still held a row that had not published its count, each costing a blocking poll): during the
+  // pending row's own walk, 1.8 us after its count went out, 33 % -- rows of a pair run 1.25 us apart on average with
+  // more jitter than that; at the top of the next row 18 %; here, after the next row's insert phase, 4 %.
+  if (FUSE && d_t >= 0 && tid < 64) d_g0 = rj_lookback_ask(f.status + (long)d_pair * nrows + d_t, d_t, lane, f.epoch);
   if (WIDE && VIRT && spr) {  // which position holds the key-less right record with the smallest pixel index (read after the next barrier)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
@@ -673,6 +659,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(2);
+  if (FUSE) {  // the pending row's place: supports of the pair's rows before it
+    if (d_t >= 0 && tid < 64) {
+      unsigned long long* d_st = f.status + (long)d_pair * nrows + d_t;
+      const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, d_g0, f.err);
+      if (lane == 0) {
+        if (d_t > 0) __hip_atomic_store(d_st, rj_granule(f.epoch, RJ_ST_PREFIX, base + d_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base = base;
+      }
+    }
+  }
 
   // ---- 3. decide every left candidate; the key table is dead already: it becomes the rank counters
   for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
