@@ -17,6 +17,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -159,6 +160,9 @@ struct gpc_hip_ctx {
   int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
   int no_partition = 0;       // GPC_HIP_NO_PARTITION: always take the radix-sort path (A/B checks)
   int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
+  int gp_log2bins = 0;        // GPC_HIP_GP_LOG2BINS = 8 .. 11: force the number of code-range bins (A/B checks)
+  int ht_hint_w = 0, ht_hint_h = 0, ht_hint_lbits = 0;  // what the hash-table planner ended on for the last image size: where it starts next time
+  int ht_lbits = 0;           // GPC_HIP_HT_LBITS = 7 .. 10: force the buckets per bin of the hash-table matcher (A/B checks)
   int gp_target = 2000;       // GPC_HIP_GP_TARGET: records per side a partition of the non-epipolar matcher aims at. Per 32 pairs of
                               // 1024x436, join + gather: 1400 -> 208 us, 1800 -> 189, 2000 / 2200 -> 182, 2600 -> 192, 3000 -> 208
   int flat_chunks = 0;        // GPC_HIP_FLAT_CHUNKS: gpc_hip_match_batch with equal chunks only (A/B checks)
@@ -175,7 +179,8 @@ struct gpc_hip_ctx {
   int fuse_min_pairs = 1;     // GPC_HIP_FUSE_MIN_PAIRS: smaller batches take the two-launch path
   int fuse_shards = 16;       // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (tuning)
   int num_cus = 0;
-  std::map<const void*, int> wgs_per_cu;  // occupancy of the persistent instantiations launched so far
+  std::map<std::pair<const void*, size_t>, int> wgs_per_cu;  // occupancy of the persistent instantiations launched so far, per LDS size
+  std::map<const void*, int> dyn_lds;     // largest dynamic-LDS size a kernel has been allowed so far (hipFuncSetAttribute once, not per call)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
   int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
@@ -268,6 +273,15 @@ struct Timed {
     c->spans.push_back(s);
   }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised only when a launch needs more than the kernel has been granted
+int allow_dyn_lds(gpc_hip_ctx* c, const void* fn, size_t bytes) {
+  int& have = c->dyn_lds[fn];
+  if ((int)bytes <= have) return GPC_OK;
+  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = (int)bytes;
+  return GPC_OK;
+}
 
 int check_dims(int W, int H) {
   if (W <= 0 || H <= 0 || (W % 16) != 0) return GPC_E_INVALID;
@@ -630,9 +644,9 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
 #define LAUNCH_FJOIN(SPT, NT, WIDE)                                                                             \
   do {                                                                                                          \
     const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, NT, WIDE, false, true>);               \
-    int& per_cu = c->wgs_per_cu[fn_];                                                                           \
+    int& per_cu = c->wgs_per_cu[std::make_pair(fn_, flds)];                                                     \
     if (per_cu == 0) {                                                                                          \
-      if (flds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds)); \
+      if (flds > 48 * 1024) CHK(allow_dyn_lds(c, fn_, flds));                                                   \
       HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_, NT, flds));                          \
       if (per_cu < 1) per_cu = 1;                                                                               \
     }                                                                                                           \
@@ -669,7 +683,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
 #define LAUNCH_JOIN(SPT, NT, WIDE)                                                                            \
   do {                                                                                                        \
     const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, NT, WIDE>);                          \
-    if (jp.lds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jp.lds)); \
+    if (jp.lds > 48 * 1024) CHK(allow_dyn_lds(c, fn_, jp.lds));                                               \
     hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
                        (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
                        (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
@@ -780,13 +794,16 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   gpc::GpLayout L = {};
   // 256 bins (8 top code bits) up to ~1 M record slots per pair; 512 / 1024 for larger images, so that a bin of a textured
   // image still holds about a partition's worth of records (the scatter's runs get shorter: k_partition.h)
+  // ... and 2048 beyond 1920x1080
   int lb = 8;
-  while (lb < 10 && (double)g.nmax * 0.7 / (double)(1 << lb) > 2800.0) ++lb;
+  while (lb < 11 && (double)g.nmax * 0.7 / (double)(1 << lb) > 2800.0) ++lb;
+  if (c->gp_log2bins > 0) lb = c->gp_log2bins;
   if (lb > bits) lb = bits;
   L.nbins = 1 << lb;
   L.bshift = bits - lb;
   L.target = c->gp_target;  // records per side a partition aims at: half of what k_row_join<4, 1024> holds (skewed bins, zero-code rows)
   L.cap = GP_NB;
+  L.cap_hard = 2 * GP_NB;  // a bin that is large by itself (skewed top code bits) goes to the 8192-record join
   // cuts happen where a running count <= nmax passes a multiple of the target, and around bins of more than
   // GP_NB - target records (k_gp_plan); the join's grid is what the plan really made (read back with the overflow word)
   L.pmax = g.nmax / L.target + 2 * (g.nmax / (GP_NB - L.target)) + 2;
@@ -818,7 +835,10 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   {
     Timed t(c, KID_GLOBAL_KEYS);
     HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    if (L.nbins > 256)
+    if (L.nbins > 1024)
+      hipLaunchKernelGGL((gpc::k_gp_hist<false, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                         tabs, L, make_divw(W));
+    else if (L.nbins > 256)
       hipLaunchKernelGGL((gpc::k_gp_hist<false, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                          tabs, L, make_divw(W));
     else
@@ -826,30 +846,22 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
                          tabs, L, make_divw(W));
     hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                        (long)L.nbins * L.nchunk);
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_gp_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)plan_lds));
+    CHK(allow_dyn_lds(c, reinterpret_cast<const void*>(gpc::k_gp_plan), plan_lds));
     hipLaunchKernelGGL(gpc::k_gp_plan, dim3(npairs), dim3(GP_THREADS), plan_lds, c->stream, (const int32_t*)tabs,
                        (const int32_t*)c->stats.p, part, L, d_flag);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->h_flag[0] && c->h_flag[2] <= 2 * GP_NB) {
-    // Some partition is over-full, but every single bin still fits the 8192-record join (skewed top code bits on a large
-    // image): plan again for that one.
-    L.cap = 2 * GP_NB;
-    HIPCHK(c, hipMemsetAsync(part, 0, plan_bytes, c->stream));
-    hipLaunchKernelGGL(gpc::k_gp_plan, dim3(npairs), dim3(GP_THREADS), plan_lds, c->stream, (const int32_t*)tabs,
-                       (const int32_t*)c->stats.p, part, L, d_flag);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  if (c->h_flag[0]) return GPC_OK;  // the caller sorts instead
+  if (c->h_flag[0]) return GPC_OK;  // a single bin beyond 8192 records: the caller sorts instead
+  const bool big_bins = c->h_flag[2] > GP_NB;  // some partitions (single bins) need the 8192-record join
   const int maxparts = c->h_flag[1] > 0 ? c->h_flag[1] : 1;
   {
     Timed t(c, KID_GLOBAL_SORT);
-    if (L.nbins > 256)
+    if (L.nbins > 1024)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<false, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    else if (L.nbins > 256)
       hipLaunchKernelGGL((gpc::k_gp_scatter<false, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
                          g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     else
@@ -872,23 +884,30 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     v.pmax = L.pmax;
     v.dw = make_divw(W);
     v.vtol = s->vertical_tolerance;
-    // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU; 16384 for up to 8192: one workgroup
-    const int log2s = L.cap > GP_NB ? 14 : 13;
-    const size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
+    v.min_recs = -1;
+    // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU; 16384 for up to 8192: one workgroup.
+    // Every partition goes to the 4096-record launch except the bins that are larger by themselves: those few (19 of
+    // 1024 code ranges of a 1920x1080 image with the Tau forest) get a launch of the 8192-record instantiation, in which
+    // all other workgroups return at once.  (Planning the whole batch for the larger kernel, as before, ran every
+    // partition at one workgroup per CU.)
+    int log2s = 13;
+    size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
     const int apply_filter = (mode == 0);
     const dim3 jgrid(maxparts, npairs);
 #define LAUNCH_VJOIN(SPT, WIDE)                                                                                         \
   do {                                                                                                                  \
     const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, 1024, WIDE, true>);                            \
-    HIPCHK(c, hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    CHK(allow_dyn_lds(c, fn_, lds));                                                                                    \
     hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
                        (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v, gpc::RjFuse());                              \
   } while (0)
-    if (L.cap > GP_NB) {
+    if (wide) LAUNCH_VJOIN(4, true); else LAUNCH_VJOIN(4, false);
+    if (big_bins) {
+      v.min_recs = GP_NB;
+      log2s = 14;
+      lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
       if (wide) LAUNCH_VJOIN(8, true); else LAUNCH_VJOIN(8, false);
-    } else {
-      if (wide) LAUNCH_VJOIN(4, true); else LAUNCH_VJOIN(4, false);
     }
 #undef LAUNCH_VJOIN
     hipLaunchKernelGGL(gpc::k_gp_gather, dim3((maxparts + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
@@ -953,51 +972,85 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   *done = false;
   if (H >= HTJ_MAXH) return GPC_OK;  // positions are packed y << 14 | x
   gpc::GpLayout L = {};
-  // bins of 1024 buckets (210 of them) up to ~1 M record slots per pair; 512 / 256 buckets per bin for larger images
+  // Bins of 1024 buckets (210 of them) up to ~1 M record slots per pair, 512 / 256 / 128 buckets per bin for larger
+  // images: Hashmatch's buckets are `state % 214673`, so bins fill evenly and the estimate (70 % of the pixels are
+  // candidates) may aim at 3500 of the 4096 records a workgroup takes.  The histogram then tells the truth: k_ht_check
+  // reports the batch's largest bin, and a bin that does not fit sends the planning round again with as many fewer
+  // buckets per bin as that takes (one more histogram, ~0.1 ms per 8 pairs of 1920x1080) instead of the whole batch to the
+  // radix path; only a bin that stays too large at 128 buckets -- one state repeated thousands of times (striped images)
+  // or more than ~6 M candidates -- goes on to the 8192-record kernel (one workgroup per CU) or, beyond that, the radix path.
   int lbits = HTJ_LBITS;
-  while (lbits > 8 && (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0) --lbits;  // a bin holds up to 4096
-  // ... or 8192 records (k_ht_join<8>: one workgroup per CU) where 839 bins are still too few
-  const int rpt = (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 2800.0 ? 8 : 4;
-  L.bshift = lbits;
-  L.nbins = (int)((HM_BUCKETS + (1u << lbits) - 1) >> lbits);  // 210 / 420 / 839
+  while (lbits > 7 && (double)g.nmax * 0.7 / (double)((HM_BUCKETS >> lbits) + 1) > 3500.0) --lbits;
+  if (c->ht_hint_w == W && c->ht_hint_h == H && c->ht_hint_lbits > 0 && c->ht_hint_lbits < lbits) lbits = c->ht_hint_lbits;
+  if (c->ht_lbits > 0) lbits = c->ht_lbits;
+  int rpt = 4;
   L.epi = s->epipolar_mode ? 1 : 0;
   const int rows = H - 2 * GPC_R;
   L.rows_per_chunk = rows >= 64 ? c->rows_per_chunk : (rows + 3) / 4;
   L.nchunk = (rows + L.rows_per_chunk - 1) / L.rows_per_chunk;
-  const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
-  const size_t cnt_ints = (size_t)npairs * L.nbins;
-  CHK(ensure(c, c->gpart, sizeof(int32_t) * (tab_ints + cnt_ints + 4)));
   CHK(ensure(c, c->staged, sizeof(uint2) * (size_t)(g.nmax / 2) * npairs));
   if (!c->h_flag) HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
-  int32_t* tabs = (int32_t*)c->gpart.p;
-  int32_t* bincnt = tabs + tab_ints;
-  int32_t* d_flag = bincnt + cnt_ints;
   const uint32_t* codes = (const uint32_t*)c->codes.p;
   const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;
   uint32_t* keys = (uint32_t*)c->gkeys[0].p;
   uint32_t* vals = (uint32_t*)c->gvals[0].p;
   dim3 cgrid(L.nchunk, 2, npairs);
-  {
-    Timed t(c, KID_GLOBAL_KEYS);
-    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t), c->stream));
-    if (L.nbins > 256)
-      hipLaunchKernelGGL((gpc::k_gp_hist<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
-                         tabs, L, make_divw(W));
-    else
-      hipLaunchKernelGGL((gpc::k_gp_hist<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
-                         tabs, L, make_divw(W));
-    hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
-                       (long)L.nbins * L.nchunk);
-    hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
-                       (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * rpt, d_flag);
-    HIPCHK(c, hipGetLastError());
+  int32_t *tabs = nullptr, *bincnt = nullptr;
+  for (int attempt = 0;; ++attempt) {
+    L.bshift = lbits;
+    L.nbins = (int)((HM_BUCKETS + (1u << lbits) - 1) >> lbits);  // 210 / 420 / 839 / 1678
+    const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
+    const size_t cnt_ints = (size_t)npairs * L.nbins;
+    CHK(ensure(c, c->gpart, sizeof(int32_t) * (tab_ints + cnt_ints + 4)));
+    tabs = (int32_t*)c->gpart.p;
+    bincnt = tabs + tab_ints;
+    int32_t* d_flag = bincnt + cnt_ints;
+    {
+      Timed t(c, KID_GLOBAL_KEYS);
+      HIPCHK(c, hipMemsetAsync(d_flag, 0, 2 * sizeof(int32_t), c->stream));
+      if (L.nbins > 1024)
+        hipLaunchKernelGGL((gpc::k_gp_hist<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                           tabs, L, make_divw(W));
+      else if (L.nbins > 256)
+        hipLaunchKernelGGL((gpc::k_gp_hist<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                           tabs, L, make_divw(W));
+      else
+        hipLaunchKernelGGL((gpc::k_gp_hist<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
+                           tabs, L, make_divw(W));
+      hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
+                         (long)L.nbins * L.nchunk);
+      hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
+                         (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * 4, d_flag);
+      HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->h_flag[0]) {  // every bin fits the 4096-record kernel
+      c->ht_hint_w = W;
+      c->ht_hint_h = H;
+      c->ht_hint_lbits = lbits;
+      break;
+    }
+    const int maxbin = c->h_flag[1];
+    // halving the buckets per bin halves an evenly filled bin: how many halvings bring the largest one under 3900?
+    int want = lbits;
+    while (want > 7 && (maxbin >> (lbits - want)) > 3900) --want;
+    if (want < lbits && c->ht_lbits == 0 && attempt < 3) {
+      lbits = want;
+      continue;
+    }
+    if (maxbin <= HTJ_THREADS * 8) {  // the 8192-record kernel takes what is left (one workgroup per CU)
+      rpt = 8;
+      break;
+    }
+    return GPC_OK;  // the caller sorts instead
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (*c->h_flag) return GPC_OK;  // the caller sorts instead
   {
     Timed t(c, KID_GLOBAL_SORT);
-    if (L.nbins > 256)
+    if (L.nbins > 1024)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+    else if (L.nbins > 256)
       hipLaunchKernelGGL((gpc::k_gp_scatter<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
                          g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
     else
@@ -1026,8 +1079,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     const size_t lds = (size_t)8 * HTJ_THREADS * rpt;
 #define LAUNCH_HTJ(RPT)                                                                                                  \
   do {                                                                                                                   \
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc::k_ht_join<RPT>),                                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+    CHK(allow_dyn_lds(c, reinterpret_cast<const void*>(gpc::k_ht_join<RPT>), lds));                                      \
     hipLaunchKernelGGL(gpc::k_ht_join<RPT>, dim3(L.nbins, npairs), dim3(HTJ_THREADS), lds, c->stream, a);                \
   } while (0)
     if (rpt == 8) LAUNCH_HTJ(8); else LAUNCH_HTJ(4);
@@ -1165,6 +1217,14 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (const char* e = getenv("GPC_HIP_GP_TARGET")) {
     const int v = atoi(e);
     if (v >= 256 && v <= 3500) c->gp_target = v;
+  }
+  if (const char* e = getenv("GPC_HIP_GP_LOG2BINS")) {
+    const int v = atoi(e);
+    if (v >= 8 && v <= 11) c->gp_log2bins = v;
+  }
+  if (const char* e = getenv("GPC_HIP_HT_LBITS")) {
+    const int v = atoi(e);
+    if (v >= 7 && v <= 10) c->ht_lbits = v;
   }
   if (const char* e = getenv("GPC_HIP_ROWS_PER_CHUNK")) {
     const int v = atoi(e);

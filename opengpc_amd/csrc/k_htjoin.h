@@ -92,6 +92,7 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
     const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
     const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
     if (nl + nr > cap) atomicOr(overflow, 1);
+    atomicMax(overflow + 1, nl + nr);  // the batch's largest bin: the host sizes its next attempt by it
   }
 }
 

@@ -32,7 +32,7 @@
 
 namespace gpc {
 
-#define GP_MAXBINS 1024   // histogram / scatter kernels come for 256 and 1024 bins (template MB).  256 = 8 top code bits is the
+#define GP_MAXBINS 2048   // histogram / scatter kernels come for 256, 1024 and 2048 bins (template MB).  256 = 8 top code bits is the
                           // rule: more destinations make the scatter's runs too short to coalesce (measured per 32 pairs:
                           // 4096 bins 445 us, 1024: 337, 512: 262, 256: 181 -- before the tiles were staged through LDS);
                           // images beyond ~1 M pixels take 512 or 1024 so that a bin still fits one workgroup's LDS
@@ -50,7 +50,8 @@ namespace gpc {
 //                                       [2] largest bin (records of one side)
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
-  int cap;                       // records per side a partition may hold
+  int cap;                       // records per side a partition aims to stay below: bins larger than cap - target stand alone
+  int cap_hard;                  // records per side the largest join kernel takes (a single bin beyond it: overflow)
   int epi;                       // HT only: the state carries the row (epipolar mode)
   long ps;                       // ints per pair in the plan blocks
   int o_off, o_rowcnt, o_misc;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
       blk[g.o_off + g.pmax + 1 + p] = s_off[g.pmax + 1 + p];
       if (p < (int)nparts) {
         const int nl = s_off[p + 1] - s_off[p], nr = s_off[g.pmax + 1 + p + 1] - s_off[g.pmax + 1 + p];
-        if (nl > g.cap || nr > g.cap) over = 1;
+        if (nl > g.cap_hard || nr > g.cap_hard) over = 1;
         if (nr > 0) last_r = p;
       }
     }

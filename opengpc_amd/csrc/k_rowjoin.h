@@ -162,6 +162,8 @@ struct RjVirt {
   int o_off, o_rowcnt, o_misc, pmax;
   GpcDivW dw;
   int vtol;
+  int min_recs;           // this launch takes the partitions with more than min_recs records on a side (and at most NT*SPT):
+                          // the few bins that are large by themselves go to the 8192-slot instantiation, the rest to the 4096 one
 };
 
 // FUSE (epipolar rows only): the kernel also does what k_gather_rows did -- it writes the row's supports straight to
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     const int offr = vblk[v.o_off + v.pmax + 1 + p];
     v_nl = vblk[v.o_off + p + 1] - v_offl;
     v_nr = vblk[v.o_off + v.pmax + 1 + p + 1] - offr;
-    if (v_nl > NB || v_nr > NB) return;  // k_gp_plan has raised the overflow flag: the host takes the radix path
+    if (v_nl > NB || v_nr > NB) return;  // another launch's partition (or k_gp_plan has raised the overflow flag: the host takes the radix path)
+    if (max(v_nl, v_nr) <= v.min_recs) return;
     vkl = v.keys + pair * v.recs + v_offl;
     vkr = v.keys + pair * v.recs + v.recs / 2 + offr;
     vvl = v.vals + pair * v.recs + v_offl;
