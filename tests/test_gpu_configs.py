@@ -428,3 +428,80 @@ def test_4k_pair_in_the_device_wide_modes(ctx, forest_paths):
         # (the reference's 214673-bucket table is far over-full at this size: 10 records per bucket kept of ~53)
         assert st == 0 and (nl, nr) == ncand and n == len(want) and n > (100 if ht else 100000)
         assert np.array_equal(got, want.astype(got.dtype))
+
+
+def test_fused_join_equals_the_two_launch_path(oracle, forest_paths):
+    """The join that writes the supports itself (k_row_join<..., FUSE>: rows drawn from ticket counters, the rows'
+    places settled by a look-back between workgroups, 12-byte records / packed words / correspondences written in place)
+    against join + k_gather_rows as two launches (GPC_HIP_NO_FUSE) and the oracle: batches whose rows are in flight in
+    different numbers per pair (1, 3, 40 pairs), widths of every threads-per-row instantiation, a capacity that cuts
+    the output in the middle of a row, repeated launches on one context (ticket counters and launch epochs carry
+    over), the packed device entry point and stereoMatch's correspondences."""
+    import torch
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_batch, synth_pair
+    from oracle.pyoracle import Oracle
+    fast = Oracle(fast=True)
+    dev = torch.device("cuda", 0)
+    os.environ["GPC_HIP_NO_FUSE"] = "1"
+    try:
+        two = g.Context(0)
+    finally:
+        del os.environ["GPC_HIP_NO_FUSE"]
+    one = g.Context(0)
+    try:
+        s = g.Settings.sparsematch()
+        for (W, H, B) in ((1024, 436, 3), (1024, 120, 40), (528, 64, 5), (2064, 60, 2), (3840, 48, 1), (96, 40, 7)):
+            Lh, Rh = synth_batch(W, H, list(range(B)))
+            rc, f = fast.read_forest(forest_paths["tau"], W, H)
+            cap_full = (W - 26) * (H - 26)
+            want = [fast.match_pair(Lh[i], Rh[i], f, sparsematch_settings()) for i in range(B)]
+            d_L, d_R = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
+            for cap in (cap_full, max(1, len(want[0][0]) // 2 + 3)):
+                outs = []
+                for ctx in (one, two):
+                    ctx.load_forest(forest_paths["tau"], W, H)
+                    d_out = torch.zeros((B, cap, 3), dtype=torch.int32, device=dev)
+                    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+                    d_nc = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize(dev)
+                    for _ in range(3):  # the same launch again and again: counters and epochs carry over
+                        ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, s, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                                               d_nc.data_ptr())
+                    ctx.synchronize()
+                    outs.append((d_out.cpu().numpy(), d_cnt.cpu().numpy(), d_nc.cpu().numpy()))
+                (o1, c1, n1), (o2, c2, n2) = outs
+                assert np.array_equal(c1, c2) and np.array_equal(n1, n2) and np.array_equal(o1, o2)
+                for i in range(B):
+                    w, nl, nr = want[i]
+                    assert c1[i] == len(w) and tuple(n1[i]) == (nl, nr)
+                    k = min(cap, len(w))
+                    assert np.array_equal(o1[i, :k, 0], w["x"][:k]) and np.array_equal(o1[i, :k, 1], w["y"][:k])
+                    assert np.array_equal(o1[i, :k, 2].view(np.float32), w["d"][:k])
+            # packed words + row counts left in HBM (the fused join writes them with the pair's own stride)
+            d_pk = torch.zeros((B, cap_full), dtype=torch.int32, device=dev)
+            d_rows = torch.zeros((B, H), dtype=torch.int32, device=dev)
+            d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            one.load_forest(forest_paths["tau"], W, H)
+            one.match_batch_device_packed(d_L.data_ptr(), d_R.data_ptr(), W, H, B, s, d_pk.data_ptr(), cap_full, d_rows.data_ptr(),
+                                          d_cnt.data_ptr())
+            one.synchronize()
+            pk, rows, cnt = d_pk.cpu().numpy().view(np.uint32), d_rows.cpu().numpy(), d_cnt.cpu().numpy()
+            for i in range(B):
+                w = want[i][0]
+                assert cnt[i] == len(w) and rows[i, 13:H - 13].sum() == len(w)
+                got = g.capi.expand_packed(pk[i], rows[i], len(w))
+                assert np.array_equal(got, w.astype(got.dtype))
+        # stereoMatch (correspondences, no disparity filter) goes through the same join in its third output mode
+        W, H = 272, 61
+        L, R = synth_pair(W, H, 4, 9)
+        rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+        res = []
+        for ctx in (one, two):
+            ctx.load_forest(forest_paths["zero"], W, H)
+            res.append(ctx.stereo_match(ctx.preprocess(L, 5), ctx.preprocess(R, 5), g.Settings(5, 128, 0, True, False, 1)))
+        assert res[0][1] == res[1][1] and res[0][1] > 0 and np.array_equal(res[0][0], res[1][0])
+    finally:
+        one.close()
+        two.close()
