@@ -22,10 +22,11 @@ def main():
                 if "gpc::" in name:
                     agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     summ = {k: {c: round(sum(v) / len(v)) for c, v in d.items()} for k, d in agg.items()}
-    os.makedirs(os.path.join(ROOT, "profiles", "r02_pmc"), exist_ok=True)
+    pmc_dir = os.path.join(ROOT, "profiles", tag.split("_")[0] + "_pmc")   # profiles/r03_pmc for tag r03_a
+    os.makedirs(pmc_dir, exist_ok=True)
     json.dump({"_comment": "rocprofv3 --pmc per-launch averages, one counter group per run (tools/pmc_collect.sh); "
                            "workload %d pairs %dx%d; FETCH_SIZE / WRITE_SIZE in KiB" % (B, W, H), "kernels": summ},
-              open(os.path.join(ROOT, "profiles", "r02_pmc", "%s_pmc_summary.json" % tag), "w"), indent=1)
+              open(os.path.join(pmc_dir, "%s_pmc_summary.json" % tag), "w"), indent=1)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     traffic["_comment"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes "

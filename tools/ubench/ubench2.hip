@@ -114,6 +114,67 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
                         "ds_read2_b32 %6, %8 offset0:144 offset1:145\n\tds_read2_b32 %7, %8 offset0:208 offset1:209\n\ts_waitcnt lgkmcnt(0)"
                         : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(addr));)
       r0 += q0.x + q1.y + q2.x + q3.y + q4.x + q5.y + q6.x + q7.y;
+    } else if (MODE >= 30 && MODE <= 34) {
+      // one fern test over a wave's 4 rows x 4 px: 24 VALU beside the LDS reads of both taps --
+      // 30: 8 ds_read_b32 (rows stored one after the other: k_hash as it is); 31 / 32 / 33: 5 / 4 / 6 ds_read_b64 (rows stored
+      // in interleaved pairs: a tap whose first row is even takes 2 reads for 4 rows, an odd one 3)
+      const uint32_t addr = (uint32_t)(uintptr_t)lds + (tid & 63) * (MODE == 30 ? 4 : 8) + ((it & 3) << 11);
+#define VALU24_K15                                                                                                            \
+  "v_and_b32 %2, %15, %2\n\tv_or_b32 %3, %15, %3\n\tv_sub_u32 %4, %15, %4\n\tv_xor_b32 %5, %15, %5\n\tv_lshrrev_b32 %6, 1, %6\n\t"   \
+  "v_bitop3_b32 %7, %15, %7, %7 bitop3:0xd8\n\tv_and_b32 %2, %15, %2\n\tv_or_b32 %3, %15, %3\n\tv_sub_u32 %4, %15, %4\n\t"          \
+  "v_xor_b32 %5, %15, %5\n\tv_lshrrev_b32 %6, 1, %6\n\tv_bitop3_b32 %7, %15, %7, %7 bitop3:0xd8\n\t"                                \
+  "v_and_b32 %2, %15, %2\n\tv_or_b32 %3, %15, %3\n\tv_sub_u32 %4, %15, %4\n\tv_xor_b32 %5, %15, %5\n\tv_lshrrev_b32 %6, 1, %6\n\t"   \
+  "v_bitop3_b32 %7, %15, %7, %7 bitop3:0xd8\n\tv_and_b32 %2, %15, %2\n\tv_or_b32 %3, %15, %3\n\tv_sub_u32 %4, %15, %4\n\t"          \
+  "v_xor_b32 %5, %15, %5\n\tv_lshrrev_b32 %6, 1, %6\n\tv_bitop3_b32 %7, %15, %7, %7 bitop3:0xd8\n\ts_waitcnt lgkmcnt(0)"
+#define VALU24_K13                                                                                                            \
+  "v_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\tv_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\t"   \
+  "v_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\tv_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\t"          \
+  "v_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\tv_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\t"                                \
+  "v_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\tv_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\t"   \
+  "v_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\tv_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\t"          \
+  "v_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\tv_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\ts_waitcnt lgkmcnt(0)"
+      if (MODE == 30) {
+        uint32_t q0, q1, a0, a1, a2, a3, a4, a5;
+        REP8(asm volatile("ds_read_b32 %0, %14\n\tds_read_b32 %1, %14 offset:288\n\tds_read_b32 %8, %14 offset:576\n\t"
+                          "ds_read_b32 %9, %14 offset:864\n\tds_read_b32 %10, %14 offset:1152\n\tds_read_b32 %11, %14 offset:1440\n\t"
+                          "ds_read_b32 %12, %14 offset:1728\n\tds_read_b32 %13, %14 offset:2016\n\t" VALU24_K15
+                          : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(a0), "=&v"(a1),
+                            "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5)
+                          : "v"(addr), "v"(k));
+             r0 += q0 + a0 + a2 + a4; r1 += q1 + a1 + a3 + a5;)
+      } else {
+        u32x2 q0, q1, a0, a1, a2, a3;
+        if (MODE == 31) {
+          REP8(asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:576\n\tds_read_b64 %8, %12 offset:1152\n\t"
+                            "ds_read_b64 %9, %12 offset:1728\n\tds_read_b64 %10, %12 offset:2304\n\t" VALU24_K13
+                            : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(a0), "=&v"(a1),
+                              "=&v"(a2), "=&v"(a3)
+                            : "v"(addr), "v"(k));
+               r0 += q0.x + a0.x + a2.y; r1 += q1.y + a1.x + a3.y;)
+        } else if (MODE == 32) {
+          REP8(asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:576\n\tds_read_b64 %8, %12 offset:1152\n\t"
+                            "ds_read_b64 %9, %12 offset:1728\n\t" VALU24_K13
+                            : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(a0), "=&v"(a1),
+                              "=&v"(a2), "=&v"(a3)
+                            : "v"(addr), "v"(k));
+               r0 += q0.x + a0.x + a2.y; r1 += q1.y + a1.x + a3.y;)
+        } else if (MODE == 34) {  // what the compiler makes of three adjacent row pairs per tap: ds_read2_b64 + ds_read_b64
+          u32x4 w0, w1;
+          REP8(asm volatile("ds_read2_b64 %8, %12 offset1:72\n\tds_read_b64 %0, %12 offset:1152\n\t"
+                            "ds_read2_b64 %9, %12 offset0:1 offset1:73\n\tds_read_b64 %1, %12 offset:1160\n\t" VALU24_K13
+                            : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(w0), "=&v"(w1),
+                              "=&v"(a2), "=&v"(a3)
+                            : "v"(addr), "v"(k));
+               r0 += q0.x + w0.x + w0.w; r1 += q1.y + w1.y + w1.z;)
+        } else {
+          REP8(asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:576\n\tds_read_b64 %8, %12 offset:1152\n\t"
+                            "ds_read_b64 %9, %12 offset:1728\n\tds_read_b64 %10, %12 offset:2304\n\tds_read_b64 %11, %12 offset:2880\n\t" VALU24_K13
+                            : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(a0), "=&v"(a1),
+                              "=&v"(a2), "=&v"(a3)
+                            : "v"(addr), "v"(k));
+               r0 += q0.x + a0.x + a2.y; r1 += q1.y + a1.x + a3.y;)
+        }
+      }
     } else if (MODE == 24) {  // LDS reads beside VALU (the hash kernel's mix: 2 ds_read_b32 per 6 VALU)
       const uint32_t addr = (uint32_t)(uintptr_t)lds + (tid & 63) * 4 + ((it & 3) << 11);
       uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
@@ -162,7 +223,10 @@ int main() {
     {"v_cmp+v_addc (pairs)", 15, 64}, {"swar test mix (8 valu)", 16, 64},
     {"ds_read_b32 linear", 20, 64}, {"ds_read_b64 linear", 21, 64}, {"ds_read_b128 linear", 22, 64}, {"ds_read_u8 linear", 23, 64},
     {"2 ds_read_b32 + 6 valu", 24, 64}, {"ds_read_b64 addr%8==4", 25, 64}, {"ds_read_b128 addr%16==4", 26, 64},
-    {"ds_read_b128 addr%16==8", 27, 64}, {"ds_read2_b32 adjacent", 28, 64}, {"ds_read2_b32 adj addr%8==4", 29, 64}};
+    {"ds_read_b128 addr%16==8", 27, 64}, {"ds_read2_b32 adjacent", 28, 64}, {"ds_read2_b32 adj addr%8==4", 29, 64},
+    // per_iter = 8 tests: the columns read "per fern test over 4 rows x 4 px"
+    {"test: 8 ds_read_b32 + 24 valu", 30, 8}, {"test: 5 ds_read_b64 + 24 valu", 31, 8}, {"test: 4 ds_read_b64 + 24 valu", 32, 8},
+    {"test: 6 ds_read_b64 + 24 valu", 33, 8}, {"test: 2 (read2_b64 + read_b64) + 24 valu", 34, 8}};
   for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     printf("== %d workgroups of 256 threads per CU (%d waves/SIMD)\n", wg_per_cu, wg_per_cu);
@@ -171,7 +235,7 @@ int main() {
       switch (c.mode) {
 #define RUN(M) case M: r = run<M>(d_out, d_cyc, blocks, iters); break;
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16)
-        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29)
+        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34)
         default: continue;
       }
       // cycles per instruction as one wave sees it, and per SIMD (divide by the waves sharing the SIMD);
