@@ -83,6 +83,7 @@ struct ContextHolder {
   // FilterMask last uploaded (the reference passes it by value into every call)
   gpc_filter_mask uploaded;
   bool have = false;
+  size_t support_hint = 0;  // supports of this thread's last matchPair call (+ slack): how large the next result array starts
   ~ContextHolder() {
     if (ctx) gpc_hip_destroy(ctx);
   }
@@ -218,7 +219,13 @@ class Forest {
     detail::ContextHolder& h = detail::holder();
     upload(h, forestmask);
     const gpc_settings s = settings.toC();
-    std::vector<ndb::Support> supp((size_t)simg.rows() * simg.cols() / 2 + 1);
+    // The array is value-initialised element by element (std::vector) before the library fills it: sized by the last
+    // call's count rather than by the worst case (one support per pixel), and never so small that a textured pair needs
+    // the call twice (the second attempt below; W*H/2 records were too few for the 1024x436 test pair and doubled its time).
+    const size_t worst = (size_t)simg.rows() * simg.cols();
+    size_t cap0 = h.support_hint ? h.support_hint : worst * 3 / 4 + 1;
+    if (cap0 > worst + 1) cap0 = worst + 1;
+    std::vector<ndb::Support> supp(cap0);
     int n = 0;
     int st = gpc_hip_match_pair(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s,
                                 reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
@@ -230,6 +237,7 @@ class Forest {
                               candidatesR);
     }
     if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_match_pair");
+    h.support_hint = (size_t)n + (size_t)n / 8 + 1024;
     supp.resize(n);
     return supp;
   }

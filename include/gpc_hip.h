@@ -181,6 +181,8 @@ int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* ra
  * settings->num_threads if > 1, else the CPUs this process may use -- divided by LOCAL_WORLD_SIZE when a launcher
  * starts one process per GPU -- less the feeding thread, between 2 and 8. */
 int gpc_hip_host_threads(const gpc_hip_ctx* ctx);
+/* The NUMA node of the host this context's GPU hangs off (the expansion workers are bound to its CPUs), -1 if unknown. */
+int gpc_hip_host_numa_node(const gpc_hip_ctx* ctx);
 
 /* ---- packed results ------------------------------------------------------------ */
 /* Forest::rectifiedMatch (inference.hpp:375-393) in epipolar mode emits supports row by row, so a support

@@ -63,6 +63,8 @@ def host_info(ctx):
     info = {"cpu_model": model, "cpus_visible": len(os.sched_getaffinity(0)), "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
     try:
         info["expand_threads"] = int(ctx.L.gpc_hip_host_threads(ctx.h))
+        info["gpu_numa_node"] = int(ctx.L.gpc_hip_host_numa_node(ctx.h))
+        info["workers_bound_to_gpu_node"] = info["gpu_numa_node"] >= 0
     except Exception:
         pass
     return info
