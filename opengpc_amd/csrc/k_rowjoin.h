@@ -674,7 +674,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
 
   // ---- 3. decide every left candidate; the key table is dead already: it becomes the rank counters
-  for (int i = tid; i <= NB; i += NT) r_cnt[i] = 0u;
+  {  // NB + 1 counters: SPT consecutive ones per thread (16-byte stores where SPT is 4: one LDS instruction instead of five)
+    uint32_t z0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
+    if (SPT % 4 == 0) {
+#pragma unroll
+      for (int q = 0; q < SPT / 4; ++q) reinterpret_cast<uint4*>(r_cnt)[tid * (SPT / 4) + q] = make_uint4(z0, z0, z0, z0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) r_cnt[tid * SPT + q] = z0;
+    }
+    if (tid == 0) r_cnt[NB] = z0;
+  }
   uint32_t okm = 0u;  // bit j = pixel slot j is a match
   uint32_t xr[SPT];
 #pragma unroll
@@ -796,10 +807,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) {
-      const uint32_t s0 = r_cnt[rb[j]], e0 = r_cnt[rb[j] + 1];
+      // (two plain ds_read_b32: for neighbouring words the compiler emits ds_read2_b32, which issues 3.6 times slower than
+      // one ds_read_b32 on gfx950 -- profiles/r03_ubench2_issue_rates.txt -- and it unrolls the walk 16-fold with them)
+      uint32_t bidx = rb[j];
+      const uint32_t s0 = r_cnt[bidx];
+      asm volatile("" : "+v"(bidx));
+      const uint32_t e0 = r_cnt[bidx + 1];
       uint32_t rank = s0;
       const uint32_t cj = kl[j] - 1u;
-      for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cj);
+      if (e0 - s0 > 1u) {  // a match alone in its bucket (four of five) has its rank already
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cj);
+      }
       dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
     }
   if (!FUSE && tid == 0) {

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
                         "ds_read2_b32 %6, %8 offset0:144 offset1:145\n\tds_read2_b32 %7, %8 offset0:208 offset1:209\n\ts_waitcnt lgkmcnt(0)"
                         : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(addr));)
       r0 += q0.x + q1.y + q2.x + q3.y + q4.x + q5.y + q6.x + q7.y;
-    } else if (MODE >= 30 && MODE <= 34) {
+    } else if (MODE >= 30 && MODE <= 35) {
       // one fern test over a wave's 4 rows x 4 px: 24 VALU beside the LDS reads of both taps --
       // 30: 8 ds_read_b32 (rows stored one after the other: k_hash as it is); 31 / 32 / 33: 5 / 4 / 6 ds_read_b64 (rows stored
       // in interleaved pairs: a tap whose first row is even takes 2 reads for 4 rows, an odd one 3)
@@ -133,7 +133,16 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
   "v_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\tv_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\t"   \
   "v_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\tv_and_b32 %2, %13, %2\n\tv_or_b32 %3, %13, %3\n\tv_sub_u32 %4, %13, %4\n\t"          \
   "v_xor_b32 %5, %13, %5\n\tv_lshrrev_b32 %6, 1, %6\n\tv_bitop3_b32 %7, %13, %7, %7 bitop3:0xd8\n\ts_waitcnt lgkmcnt(0)"
-      if (MODE == 30) {
+      if (MODE == 35) {  // k_hash as the compiler emits it: two rows per ds_read2_b32 (row stride 72 dwords), 4 per test
+        u32x2 q0, q1, a0, a1;
+        const uint32_t addr4 = (uint32_t)(uintptr_t)lds + (tid & 63) * 4 + ((it & 3) << 11);
+        REP8(asm volatile("ds_read2_b32 %0, %12 offset1:72\n\tds_read2_b32 %1, %12 offset0:144 offset1:216\n\t"
+                          "ds_read2_b32 %8, %12 offset0:3 offset1:75\n\tds_read2_b32 %9, %12 offset0:147 offset1:219\n\t" VALU24_K13
+                          : "=&v"(q0), "=&v"(q1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(a0), "=&v"(a1),
+                            "=&v"(r0), "=&v"(r1)
+                          : "v"(addr4), "v"(k));
+             r2 += q0.x + a0.y; r3 += q1.y + a1.x;)
+      } else if (MODE == 30) {
         uint32_t q0, q1, a0, a1, a2, a3, a4, a5;
         REP8(asm volatile("ds_read_b32 %0, %14\n\tds_read_b32 %1, %14 offset:288\n\tds_read_b32 %8, %14 offset:576\n\t"
                           "ds_read_b32 %9, %14 offset:864\n\tds_read_b32 %10, %14 offset:1152\n\tds_read_b32 %11, %14 offset:1440\n\t"
@@ -226,7 +235,8 @@ int main() {
     {"ds_read_b128 addr%16==8", 27, 64}, {"ds_read2_b32 adjacent", 28, 64}, {"ds_read2_b32 adj addr%8==4", 29, 64},
     // per_iter = 8 tests: the columns read "per fern test over 4 rows x 4 px"
     {"test: 8 ds_read_b32 + 24 valu", 30, 8}, {"test: 5 ds_read_b64 + 24 valu", 31, 8}, {"test: 4 ds_read_b64 + 24 valu", 32, 8},
-    {"test: 6 ds_read_b64 + 24 valu", 33, 8}, {"test: 2 (read2_b64 + read_b64) + 24 valu", 34, 8}};
+    {"test: 6 ds_read_b64 + 24 valu", 33, 8}, {"test: 2 (read2_b64 + read_b64) + 24 valu", 34, 8},
+    {"test: 4 ds_read2_b32 (rows 72 dwords apart) + 24 valu", 35, 8}};
   for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     printf("== %d workgroups of 256 threads per CU (%d waves/SIMD)\n", wg_per_cu, wg_per_cu);
@@ -235,7 +245,7 @@ int main() {
       switch (c.mode) {
 #define RUN(M) case M: r = run<M>(d_out, d_cyc, blocks, iters); break;
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16)
-        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34)
+        RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35)
         default: continue;
       }
       // cycles per instruction as one wave sees it, and per SIMD (divide by the waves sharing the SIMD);
