@@ -249,7 +249,8 @@ def main():
 
     # per-kernel table: serial steps with every kernel bracketed, run right behind the timed windows (the clocks are
     # where the windows left them: the first launches after an idle second run several per cent slower)
-    ktimes = bracket_all(10)
+    bracket_all(5)            # (the first launches with every kernel bracketed run a few per cent slower: not counted)
+    ktimes = bracket_all(20)
 
     counts = d_counts.cpu().numpy().astype(np.int64)
     ncand = d_ncand.cpu().numpy().astype(np.int64)

@@ -7,19 +7,22 @@
 // Layout of the work (gfx950):
 //   * a 512-thread workgroup owns a 256 x 32 output tile; the (256+32) x (32+26) smooth
 //     window is staged once into LDS with 16-byte coalesced loads;
-//   * a LANE owns 4 horizontally adjacent pixels, a WAVE one 256-pixel row segment per step
-//     and 4 rows in total.  The window is kept in LDS FOUR times, copy s shifted left by s
-//     bytes, so a tap for 4 pixels is ONE ALIGNED ds_read_b32 from copy (dx & 3) at
-//     `lane base + SGPR offset + row immediate` (unaligned LDS dwords work on gfx950 but
-//     measured ~20x slower).  64 lanes read 256 contiguous bytes: conflict-free, and 4x fewer
-//     LDS instructions than a byte gather.  VALU issue bounds this kernel: its instruction count
-//     x 4 cycles per wave64 instruction is its run time;
-//   * the four unsigned byte compares of a test are done SWAR in 4 VALU ops (and, or, sub,
-//     v_bitop3) and shifted into byte planes exactly like the reference's out[0..3] registers
-//     (2 more: 6 ops per test and 4 pixels, + 2 address adds per test); the planes are
-//     transposed into 4 codes with v_perm_b32 at the end;
-//   * the tests (packed LDS offsets, tau) arrive as a by-value kernel argument and live in
-//     SGPRs; the test loop is fully unrolled in branch-free groups so reads are batched.
+//   * a LANE owns 4 horizontally adjacent pixels, a WAVE one 256-pixel row segment in 4 consecutive rows.
+//     The window is kept in LDS FOUR times, copy s shifted left by s bytes, so a tap for 4 pixels is ONE ALIGNED
+//     dword of copy (dx & 3) at `lane base + scalar offset + row immediate` (unaligned LDS dwords work on gfx950 but
+//     measured ~30x slower), and the compiler pairs the rows: two rows of a tap, 72 dwords apart, per ds_read2_b32 --
+//     the cheapest LDS read form on this chip for this pattern (profiles/r03_ubench2_issue_rates.txt: a test's taps +
+//     its 24 VALU take 8.7 ns per CU this way, 9.2-9.4 ns as aligned ds_read_b64 of row-interleaved storage, 11.4 ns as
+//     eight ds_read_b32).  64 lanes read 256 contiguous bytes: conflict-free;
+//   * the four unsigned byte compares of a test are done SWAR in 4 VALU ops (or, and, sub, v_bitop3) and shifted
+//     into byte planes exactly like the reference's out[0..3] registers (2 more: 6 ops per test and 4 pixels,
+//     + 2 address adds per test); the planes are transposed into 4 codes with v_perm_b32 at the end;
+//   * the tests (packed LDS offsets, tau) are READ FROM DEVICE MEMORY with scalar loads, eight at a time (as a
+//     by-value kernel argument the 64 words stayed live in SGPRs for the whole kernel and the allocator spilled 59 of
+//     them); the test loop is fully unrolled, the taps of test t+1 are requested before test t is evaluated;
+//   * what bounds the kernel: during the tests LDS reads (2 dwords per test and 4 pixels) and the 6 VALU per test add
+//     up rather than overlap (52-56 % of a wave's time); the rest is waiting for the other waves at the two barriers
+//     per tile, staging, candidate flags and stores (profiles/r03_a_phase_stamps.txt).
 // No MFMA: this is gather/compare.
 //
 // Output is a dense code image (u32 per pixel): the code for candidates, GPC_NOCAND for
