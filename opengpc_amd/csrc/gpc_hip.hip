@@ -729,7 +729,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     }
     {
       Timed t(c, KID_ROW_JOIN);
-      const int rpw = c->join_rpw > 0 ? c->join_rpw : 1;
+      const int rpw = 1;  // (GPC_HIP_JOIN_RPW is accepted and ignored: the kernel takes one row per workgroup)
       const dim3 jgrid((H - 2 * GPC_R + rpw - 1) / rpw, npairs);
       const bool wide = wide_codes(c);
       snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join<%d, %d, %s>", jp.spt, jp.nt,

@@ -338,6 +338,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s, int rpw, RjVirt v, RjFuse f) {
   static_assert(!(FUSE && VIRT), "the fused output is for image rows");
+#ifndef RJ_KEEP_RPW
+  rpw = 1;  // (rows per workgroup with next-row prefetch measured within the noise of one row, DESIGN.md 7, and its eight
+            // prefetch registers put scratch into the 1024-thread instantiation: one row per workgroup it is)
+#endif
   static_assert(!(FUSE && NT * SPT > 4096), "16-bit flag words hold 12 bits of x");
   // flags of a table slot; FUSE: halfwords, two slots per word, x in the low 12 bits
   constexpr uint32_t F_LSEEN = FUSE ? 0x1000u : RJ_LSEEN, F_LDUP = FUSE ? 0x2000u : RJ_LDUP;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     const long ro = ((long)(pair * 2) * H + yy) * W;
     const uint32_t* rl = codes + ro;
     const uint32_t* rr_ = rl + (long)H * W;
-    if (FUSE) {
+    {
       // no branch around a load: with one the compiler sinks the key arithmetic into the branch and waits for every
       // pair of loads before it issues the next (four round trips per row instead of one)
       // (nor a clamp: pixel slots beyond W read into the next row -- the code image is allocated with that slack, the
@@ -470,10 +474,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const int x = j * NT + tid;
-      if (!FUSE) {
-        ncl[j] = (x < W) ? rl[x] : RJ_EMPTY;
-        ncr[j] = (x < W) ? rr_[x] : RJ_EMPTY;
-      }
       if (WIDE) {
         // the hash kernel's candidate rule (k_hash.h): candidate byte set, inside the margin (the row is)
         const bool inm = x >= GPC_R && x < W - GPC_R;
@@ -815,7 +815,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       const uint32_t e0 = r_cnt[bidx + 1];
       uint32_t rank = s0;
       const uint32_t cj = kl[j] - 1u;
+#ifdef RJ_WALK_ALWAYS
+      if (true) {
+#else
       if (e0 - s0 > 1u) {  // a match alone in its bucket (four of five) has its rank already
+#endif
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cj);
       }
