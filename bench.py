@@ -167,9 +167,15 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    gdist.init("nccl", dev)  # nccl == RCCL on ROCm; no-op for a single process
+    # GPC_DIST_BACKEND=gloo: rehearsal of the N > 1 line on a box with fewer GPUs than ranks (the ranks share the devices
+    # there are, rank r on device r mod count; RCCL refuses two ranks on one device, gloo carries the barriers instead)
+    backend = os.environ.get("GPC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    gdist.init(backend, dev)  # nccl == RCCL on ROCm; no-op for a single process
+    stat_dev = dev if backend == "nccl" else "cpu"
 
     import opengpc_amd as g
     from opengpc_amd.synth import synth_batch
@@ -179,7 +185,7 @@ def main():
     settings = g.Settings.sparsematch()
     ctxs, streams = [], []
     for _ in range(P):  # one context = one HIP stream + one set of workspaces
-        c = g.Context(local_rank)
+        c = g.Context(dev_index)
         fm = c.load_forest(args.forest, W, H)
         st = torch.cuda.Stream(device=dev)
         c.set_stream(st.cuda_stream)
@@ -303,7 +309,7 @@ def main():
     row = [float(B), float(ncand.sum()), float(counts.sum()), 1.0 if verified in (True, None) else 0.0,
            float(n_verified), 1.0 if host_ok else 0.0, float(host_threads)] + [float(t) for t in host_times] + \
           [float(t) for t in windows]
-    allr = gdist.gather_stats(row, device=dev).numpy()
+    allr = gdist.gather_stats(row, device=stat_dev).numpy()
     if float(allr[:, 3].min()) < 1.0:
         raise SystemExit("bench.py: GPU supports differ from the oracle on some rank -- refusing to report a number")
     nh = len(host_times)
@@ -439,7 +445,7 @@ def main():
         # beside the serial headline because its per-kernel event times are no longer clean
         two = None
         if world == 1 and P == 1 and not args.no_extras:
-            c2 = g.Context(local_rank)
+            c2 = g.Context(dev_index)
             c2.load_forest(args.forest, W, H)
             st2 = torch.cuda.Stream(device=dev)
             c2.set_stream(st2.cuda_stream)
