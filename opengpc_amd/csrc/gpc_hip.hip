@@ -78,6 +78,10 @@ struct ExpandJob {
   int H, y0, y1, first, limit;  // rows [y0, y1) of a pair whose supports start at index `first`; stop at `limit`
   gpc_support* out;
   int slot;
+  // a plain copy instead (pageable input images into the page-locked bounce buffer of their chunk): copy_bytes > 0
+  const void* copy_src = nullptr;
+  void* copy_dst = nullptr;
+  size_t copy_bytes = 0;
 };
 
 class ExpandPool {
@@ -147,6 +151,8 @@ struct gpc_hip_ctx {
   DevBuf packed;                  // packed results of the chunks in flight (3 slots)
   void* h_stage = nullptr;        // page-locked landing area of packed results (4 slots)
   size_t h_stage_cap = 0;
+  void* h_in = nullptr;           // page-locked bounce buffer for PAGEABLE input images (2 slots x 2 sides x a chunk)
+  size_t h_in_cap = 0;
   int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
   size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
@@ -455,7 +461,8 @@ void ExpandPool::run() {
       j = q_.front();
       q_.pop_front();
     }
-    expand_rows(j.packed, j.rows, j.y0, j.y1, j.first, j.limit, j.out);
+    if (j.copy_bytes) memcpy(j.copy_dst, j.copy_src, j.copy_bytes);
+    else expand_rows(j.packed, j.rows, j.y0, j.y1, j.first, j.limit, j.out);
     {
       std::lock_guard<std::mutex> g(m_);
       if (--pending_[j.slot & 7] == 0) done_.notify_all();
@@ -1338,6 +1345,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   }
   c->pool.stop();
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_cnt) (void)hipHostFree(c->h_cnt);
   if (c->h_flag) (void)hipHostFree(c->h_flag);
   if (c->h_err) (void)hipHostFree(c->h_err);
@@ -1907,6 +1915,23 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
   int32_t* hc = c->h_cnt;               // counts
   int32_t* hn = c->h_cnt + npairs;      // candidate counts
   CHK(batch_streams(c));
+  // Pageable input images (malloc, std::vector, ndb::Buffer): a copy engine cannot read them, and hipMemcpyAsync then stages
+  // them itself, synchronously, on the calling thread -- which serialised the whole chunk pipeline (32 pairs: 7.5 ms
+  // against 1.1 ms from page-locked memory).  The workers copy a chunk into a page-locked bounce buffer instead (two
+  // slots) while the device works on the chunks before it, and the upload runs from there.
+  // (from four pairs on: for one pair waking the workers costs more than the runtime's own staging)
+  const bool bounce = npairs >= 4 && (!device_view_of_host(rawL) || !device_view_of_host(rawR));
+  if (bounce) {
+    const size_t need = 2 * 2 * n * (size_t)chunk;
+    if (need > c->h_in_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->s_in));
+      if (c->h_in) HIPCHK(c, hipHostFree(c->h_in));
+      c->h_in = nullptr;
+      c->h_in_cap = 0;
+      HIPCHK(c, hipHostMalloc(&c->h_in, need, hipHostMallocDefault));
+      c->h_in_cap = need;
+    }
+  }
   {  // numThreads_ of the reference's settings asks for that many workers; otherwise what the process may use
     // (measured, 256 pairs: 3 .. 10 workers all keep up with the link -- 8.7 .. 8.9 ms per call, the link's 57 GB/s
     // shared by both directions being the limit; 14 workers on a 16-CPU share: 10.9 ms)
@@ -1963,8 +1988,28 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     uint8_t* d_l = (uint8_t*)c->raw.p + (size_t)(k & 1) * 2 * n * chunk;
     uint8_t* d_r = d_l + n * chunk;
     if (k >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->e_comp[(k - 2) & 3], 0));  // chunk k-2 has read this slot
-    HIPCHK(c, hipMemcpyAsync(d_l, rawL + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
-    HIPCHK(c, hipMemcpyAsync(d_r, rawR + (size_t)p0 * n, n * pc, hipMemcpyHostToDevice, c->s_in));
+    const uint8_t *srcL = rawL + (size_t)p0 * n, *srcR = rawR + (size_t)p0 * n;
+    if (bounce) {
+      uint8_t* bl = (uint8_t*)c->h_in + (size_t)(k & 1) * 2 * n * chunk;
+      uint8_t* br = bl + n * chunk;
+      if (k >= 2) HIPCHK(c, hipEventSynchronize(c->e_in[(k - 2) & 3]));  // the upload of chunk k-2 has left this bounce slot
+      const int pieces = c->pool.size() > 1 ? c->pool.size() : 1;
+      const size_t bytes = n * pc, step = (bytes / pieces + 4095) & ~(size_t)4095;
+      for (int side = 0; side < 2; ++side)
+        for (size_t at = 0; at < bytes; at += step) {
+          ExpandJob j = {};
+          j.slot = 7;  // a wait slot of its own: the landing slots of the results use 0 .. 3
+          j.copy_src = (side ? srcR : srcL) + at;
+          j.copy_dst = (side ? br : bl) + at;
+          j.copy_bytes = at + step <= bytes ? step : bytes - at;
+          c->pool.push(j);
+        }
+      c->pool.wait_slot(7);
+      srcL = bl;
+      srcR = br;
+    }
+    HIPCHK(c, hipMemcpyAsync(d_l, srcL, n * pc, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipMemcpyAsync(d_r, srcR, n * pc, hipMemcpyHostToDevice, c->s_in));
     HIPCHK(c, hipEventRecord(c->e_in[ev], c->s_in));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_in[ev], 0));
     if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_out[(k - 3) & 3], 0));  // chunk k-3 has left this result slot

@@ -111,7 +111,9 @@ def main():
                 continue
             L, R = synth_batch(W, H, list(range(B)))
             cap = 300000
-            out = None
+            # (the output array is allocated and touched ONCE either way: a fresh np.empty per call is 115 MB of first-touch
+            # page faults at 32 pairs -- 6 of the 7.5 ms "pageable" calls of earlier records were that, not the copies)
+            out = np.zeros((B, cap), g.SUPPORT_DTYPE)
             if pinned:
                 Lp, Rp = ctx.pinned_empty(L.shape, np.uint8), ctx.pinned_empty(R.shape, np.uint8)
                 Lp[:] = L
