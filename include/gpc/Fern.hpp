@@ -6,6 +6,7 @@
 // generator, in the reference's order (one sampleHyperplane per level and resample).
 #ifndef _GPC_fern
 #define _GPC_fern
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -115,7 +116,10 @@ class DeviceTriplets {
   gpc_hip_ctx* ctx() const { return ctx_; }
   gpc_hip_train_set* set() const { return set_; }
   void check(int st, const char* what) const {
-    if (st != GPC_OK) gpc::inference::detail::fail(st, ctx_, what);
+    if (st != GPC_OK) {
+      gpc::inference::detail::fail(st, ctx_, what);
+      std::abort();  // a training run cannot go on without its device set (matching calls return empty results instead)
+    }
   }
 
  private:

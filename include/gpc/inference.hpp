@@ -12,8 +12,9 @@
 //   matchPair        (extension: the whole t0..t2 region of sparsematch.cpp:45-52 in one
 //                     call, raw images in, supports out -> gpc_hip_match_pair)
 //
-// There is no CPU fallback: if no gfx950 device can be opened the first hot call prints the
-// error and aborts (the reference has no error channel on these methods either).
+// There is no CPU fallback and, like the reference, no error channel on these methods: a call that cannot run (no gfx950
+// device, a HIP error) prints the reason to std::cout and returns an EMPTY result -- the reference's own convention for
+// what it can report (readPNG -> 1, readForest -> empty mask).  GPC_HIP_ABORT_ON_ERROR=1 aborts the process instead.
 // One device context per host thread (thread_local), device chosen by GPC_HIP_DEVICE.
 #ifndef GPC_AMD_INFERENCE_HPP
 #define GPC_AMD_INFERENCE_HPP
@@ -92,14 +93,18 @@ inline void fail(int st, gpc_hip_ctx* ctx, const char* what) {
   std::cout << "gpc_hip: " << what << " failed: " << gpc_hip_status_string(st);
   if (st == GPC_E_HIP && ctx) std::cout << " (" << gpc_hip_last_error(ctx) << ")";
   std::cout << std::endl;
-  std::abort();
+  if (std::getenv("GPC_HIP_ABORT_ON_ERROR")) std::abort();
 }
 inline ContextHolder& holder() {
   static thread_local ContextHolder h;
   if (!h.ctx) {
     const char* dev = std::getenv("GPC_HIP_DEVICE");
     const int st = gpc_hip_create(dev ? std::atoi(dev) : 0, &h.ctx);
-    if (st != GPC_OK) fail(st, nullptr, "gpc_hip_create");
+    if (st != GPC_OK) {
+      fail(st, nullptr, "gpc_hip_create");
+      h.ctx = nullptr;
+      return h;  // the caller returns an empty result
+    }
     // Like the reference, the arithmetic variant is a build-time choice of the CALLER's
     // translation unit: -D_INTRINSICS_SSE (the reference's default, samples/CMakeLists.txt:13-17)
     // selects the SSE-exact kernels, its absence the *Naive ones (filter.hpp:157-282).
@@ -132,6 +137,7 @@ class Forest {
     std::vector<int> mask;
     PreprocessedImage(ndb::Buffer<uint8_t>& smooth, ndb::Buffer<uint8_t>& grad, std::vector<int>& mask)
         : smooth(smooth), grad(grad), mask(mask) {}
+    PreprocessedImage() {}  // what a call that could not run returns: no candidates
   };
   enum CorrMethod { sorting = 's', hashtable = 'h' };
 
@@ -158,6 +164,7 @@ class Forest {
     assert((settings.gradientThreshold_ >= 0 && settings.gradientThreshold_ <= 255) &&
            "gradientThreshold needs to be within 0...255");
     detail::ContextHolder& h = detail::holder();
+    if (!h.ctx) return PreprocessedImage();
     ndb::Buffer<uint8_t> smooth(img.rows(), img.cols());
     smooth.width = img.width;
     ndb::Buffer<uint8_t> grad(img.rows(), img.cols());
@@ -166,7 +173,10 @@ class Forest {
     int n = 0;
     const int st = gpc_hip_preprocess(h.ctx, img.data(), img.cols(), img.rows(), settings.gradientThreshold_,
                                       smooth.data(), grad.data(), mask.data(), (int)mask.size(), &n);
-    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_preprocess");
+    if (st != GPC_OK) {
+      detail::fail(st, h.ctx, "gpc_hip_preprocess");
+      return PreprocessedImage();
+    }
     mask.resize(n);
     return PreprocessedImage(smooth, grad, mask);
   }
@@ -179,7 +189,7 @@ class Forest {
     assert((forestmask.width == timg.smooth.cols() && forestmask.height == simg.smooth.rows()) &&
            "Targe Image: dimension does not fit dimension of supplied forest mask");
     detail::ContextHolder& h = detail::holder();
-    upload(h, forestmask);
+    if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Correspondence>();
     const gpc_settings s = settings.toC();
     std::vector<ndb::Correspondence> corr(std::min(simg.mask.size(), timg.mask.size()) + 1);
     int n = 0;
@@ -187,7 +197,10 @@ class Forest {
         h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
         timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
         reinterpret_cast<gpc_correspondence*>(corr.data()), (int)corr.size(), &n);
-    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_stereo_match");
+    if (st != GPC_OK) {
+      detail::fail(st, h.ctx, "gpc_hip_stereo_match");
+      return std::vector<ndb::Correspondence>();
+    }
     corr.resize(n);
     return corr;
   }
@@ -198,7 +211,7 @@ class Forest {
     assert((forestmask.width == simg.smooth.cols() && forestmask.height == simg.smooth.rows()) &&
            "Source Image: dimension does not fit dimension of supplied forest mask");
     detail::ContextHolder& h = detail::holder();
-    upload(h, forestmask);
+    if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
     std::vector<ndb::Support> supp(std::min(simg.mask.size(), timg.mask.size()) + 1);
     int n = 0;
@@ -206,7 +219,10 @@ class Forest {
         h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
         timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
         reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n);
-    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_rectified_match");
+    if (st != GPC_OK) {
+      detail::fail(st, h.ctx, "gpc_hip_rectified_match");
+      return std::vector<ndb::Support>();
+    }
     supp.resize(n);
     return supp;
   }
@@ -217,7 +233,7 @@ class Forest {
                                       InferenceSettings settings, int* candidatesL = nullptr,
                                       int* candidatesR = nullptr) {
     detail::ContextHolder& h = detail::holder();
-    upload(h, forestmask);
+    if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
     // The array is value-initialised element by element (std::vector) before the library fills it: sized by the last
     // call's count rather than by the worst case (one support per pixel), and never so small that a textured pair needs
@@ -236,7 +252,10 @@ class Forest {
                               reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
                               candidatesR);
     }
-    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_match_pair");
+    if (st != GPC_OK) {
+      detail::fail(st, h.ctx, "gpc_hip_match_pair");
+      return std::vector<ndb::Support>();
+    }
     h.support_hint = (size_t)n + (size_t)n / 8 + 1024;
     supp.resize(n);
     return supp;
@@ -252,7 +271,7 @@ class Forest {
     }
     return n;
   }
-  static void upload(detail::ContextHolder& h, const FilterMask& f) {
+  static bool upload(detail::ContextHolder& h, const FilterMask& f) {
     gpc_filter_mask fm;
     memset(&fm, 0, sizeof fm);
     fm.num_tests = (int)(f.mask.size() / 2);
@@ -262,11 +281,15 @@ class Forest {
     fm.type = f.type;
     fm.width = f.width;
     fm.height = f.height;
-    if (h.have && memcmp(&h.uploaded, &fm, sizeof fm) == 0) return;
+    if (h.have && memcmp(&h.uploaded, &fm, sizeof fm) == 0) return true;
     const int st = gpc_hip_set_forest(h.ctx, &fm);
-    if (st != GPC_OK) detail::fail(st, h.ctx, "gpc_hip_set_forest");
+    if (st != GPC_OK) {
+      detail::fail(st, h.ctx, "gpc_hip_set_forest");
+      return false;
+    }
     h.uploaded = fm;
     h.have = true;
+    return true;
   }
 };
 
