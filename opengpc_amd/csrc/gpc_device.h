@@ -36,9 +36,11 @@
 struct GpcForestDev {
   int32_t off[32];    // LDS DWORD offsets of a test's two taps, packed (off_a & 0xFFFF) | (off_b << 16);
                       // byte offset = (dx & 3) * HT_COPY + dy * HT_STRIDE + (dx - (dx & 3))
-  int32_t tau[32];    // (int8_t) tau, sign-extended
+  int32_t tau[32];    // (int8_t) tau, sign-extended (SSE arithmetic) / the int as given (Naive arithmetic)
   int32_t num_tests;
   int32_t type;
+  int32_t tau8[8];    // the same taus as bytes, four per word (test t: byte t & 3 of word t >> 2): the SSE kernels read a group's
+                      // eight with ONE 8-byte scalar load instead of eight words (the Tau instantiation spilled SGPRs)
 };
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }

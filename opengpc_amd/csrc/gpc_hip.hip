@@ -1488,6 +1488,7 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
     }
     f.off[t] = (offs[0] & 0xFFFF) | (offs[1] << 16);
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
+    f.tau8[t >> 2] |= (int32_t)((uint32_t)(fm->tau[t] & 0xFF) << ((t & 3) * 8));
     // gpcFilterNaive shifts the code left per test: test t ends on bit T-1-t (filter.hpp:245-249)
     const int u = fm->num_tests - 1 - t;
     fn.off[u] = f.off[t];

@@ -174,7 +174,8 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
     if (i + HT_PIPE < N && i + HT_PIPE < cnt) load(i + HT_PIPE, (i + HT_PIPE) % D);
     __builtin_amdgcn_sched_barrier(0);
     if (i < cnt) {
-      const int tau = TAU ? fp->tau[t0 + i] : 0;
+      // SSE arithmetic: the byte of tau (packed four per word); Naive: the int
+      const int tau = !TAU ? 0 : (NAIVE ? fp->tau[t0 + i] : (int)((((uint32_t)fp->tau8[(t0 + i) >> 2]) >> (((t0 + i) & 3) * 8)) & 0xFFu));
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         uint32_t av = a[i % D][r], bv = b[i % D][r];
