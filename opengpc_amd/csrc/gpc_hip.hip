@@ -194,6 +194,7 @@ struct gpc_hip_ctx {
   int32_t* h_err = nullptr;   // page-locked, device-visible: a look-back of the fused join timed out
   int32_t* d_err = nullptr;   // the device's address of that word
   int no_fuse = 0;            // GPC_HIP_NO_FUSE: join + k_gather_rows as two launches (A/B checks)
+  int fuse_always = 0;        // GPC_HIP_FUSE_ALWAYS: the fused join wherever it is possible, however small the launch (tests, A/B checks)
   int fuse_wgs = 0;           // GPC_HIP_FUSE_WGS: workgroups of the persistent join (tuning; default = what the device holds)
   int fuse_min_pairs = 1;     // GPC_HIP_FUSE_MIN_PAIRS: smaller batches take the two-launch path
   int fuse_shards = 16;       // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (tuning)
@@ -675,10 +676,21 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     if (jp.nt * jp.spt < W) return GPC_E_UNSUPPORTED;  // unreachable below check_dims' 16384 px
     // One launch for join + output (k_rowjoin.h, FUSE) where the table leaves room for the ranked words (rows up to
     // 8192 px) and the records' place follows from the rows before them alone (not the gap-free packing of `totals`)
-    const bool fuse = !c->no_fuse && npairs >= c->fuse_min_pairs && jp.spt <= 4 && (1 << jp.log2s) >= 2 * jp.nt * jp.spt &&
-                      !(po && po->totals) && (long)npairs * (H - 2 * GPC_R) < (1l << 31) - 65536;
     // keys [S+4 words] | 16-bit flags [S/2 words] | pending row's ranked words [NT*SPT]
     const size_t flds = (size_t)4 * ((1u << jp.log2s) + 4) + (size_t)2 * (1u << jp.log2s) + (size_t)4 * jp.nt * jp.spt;
+    bool fuse = !c->no_fuse && npairs >= c->fuse_min_pairs && jp.spt <= 4 && (1 << jp.log2s) >= 2 * jp.nt * jp.spt &&
+                !(po && po->totals) && (long)npairs * (H - 2 * GPC_R) < (1l << 31) - 65536;
+    if (fuse && !c->fuse_always) {
+      // The persistent launch pays off once every workgroup takes several rows (its output lags one row behind, and the
+      // last row of a workgroup is placed with a blocking look-back): measured against join + k_gather_rows,
+      // 1024x436: 1 .. 24 pairs 3-10 % slower, 32 pairs even, 48 .. 256 pairs 4-11 % faster; 1920x1080: one pair 6 % slower,
+      // 8 pairs 8 % faster; one 3840x2160 pair 9 % faster.  Rows per resident workgroup >= 6, or >= 3 for rows of
+      // 2048 px and more, is where it wins.
+      const long lds_wgs = (long)(160 * 1024 / (flds + 256)), wave_wgs = 32 / (jp.nt / 64);
+      const long resident = (long)c->num_cus * (lds_wgs < wave_wgs ? lds_wgs : wave_wgs);
+      const long rows_total = (long)npairs * (H - 2 * GPC_R);
+      fuse = rows_total >= 6 * resident || (W >= 2048 && rows_total >= 3 * resident);
+    }
     if (fuse) {
       const int nrows = H - 2 * GPC_R;
       CHK(ensure_join_state(c, (size_t)npairs * nrows));
@@ -1300,6 +1312,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
   if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
+  c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 65536) c->fuse_wgs = v;

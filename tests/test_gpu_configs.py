@@ -448,7 +448,11 @@ def test_fused_join_equals_the_two_launch_path(oracle, forest_paths):
         two = g.Context(0)
     finally:
         del os.environ["GPC_HIP_NO_FUSE"]
-    one = g.Context(0)
+    os.environ["GPC_HIP_FUSE_ALWAYS"] = "1"  # (by itself the library fuses only launches with several rows per resident workgroup)
+    try:
+        one = g.Context(0)
+    finally:
+        del os.environ["GPC_HIP_FUSE_ALWAYS"]
     try:
         s = g.Settings.sparsematch()
         for (W, H, B) in ((1024, 436, 3), (1024, 120, 40), (528, 64, 5), (2064, 60, 2), (3840, 48, 1), (96, 40, 7)):

@@ -19,6 +19,20 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def fused_ctx():
+    """A context that takes the join + output in one launch wherever it can (by itself the library picks it only for
+    launches with several rows per resident workgroup, which these small images never are)."""
+    import opengpc_amd as g
+    os.environ["GPC_HIP_FUSE_ALWAYS"] = "1"
+    try:
+        c = g.Context(0)
+    finally:
+        del os.environ["GPC_HIP_FUSE_ALWAYS"]
+    yield c
+    c.close()
+
+
 def draw_pair(rng, W, H):
     kind = rng.integers(0, 4)
     wide = W + 64
@@ -45,7 +59,7 @@ def draw_pair(rng, W, H):
 
 # GPC_FUZZ_SEEDS=N widens the sweep for a one-off soak (the default 36 take ~2 s)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("GPC_FUZZ_SEEDS", "36"))))
-def test_random_configuration(ctx, oracle, forest_paths, seed):
+def test_random_configuration(ctx, fused_ctx, oracle, forest_paths, seed):
     import opengpc_amd as g
     rng = np.random.default_rng(1000 + seed)
     W = 16 * int(rng.integers(3, 140))            # 48 .. 2224
@@ -65,6 +79,27 @@ def test_random_configuration(ctx, oracle, forest_paths, seed):
         got, n, ncand, st = ctx.match_pair(L, R, g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1))
         assert st == 0 and (nl, nr) == tuple(ncand), (W, H, forest, epipolar, hashtable, naive, thr)
         assert n == len(want) and np.array_equal(got, want.astype(got.dtype)), (W, H, forest, epipolar, hashtable, naive, thr)
+        if epipolar and not hashtable:  # the device entry point with the fused join + output: the pair, its mirror, the pair again
+            import torch
+            dev = torch.device("cuda", 0)
+            fused_ctx.set_arithmetic(naive)
+            fused_ctx.load_forest(forest_paths[forest], W, H)
+            dL = torch.from_numpy(np.stack([L, R, L])).to(dev)
+            dR = torch.from_numpy(np.stack([R, L, R])).to(dev)
+            capd = max(n, 1) + W
+            d_out = torch.zeros((3, capd, 3), dtype=torch.int32, device=dev)
+            d_cnt = torch.zeros(3, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            fused_ctx.match_batch_device(dL.data_ptr(), dR.data_ptr(), W, H, 3, g.Settings(thr, disp_high, vtol, True, False, 1),
+                                         d_out.data_ptr(), capd, d_cnt.data_ptr(), 0)
+            fused_ctx.synchronize()
+            fused_ctx.set_arithmetic(False)
+            cnt = d_cnt.cpu().numpy()
+            o = d_out.cpu().numpy()
+            assert cnt[0] == n and cnt[2] == n
+            for q in (0, 2):
+                assert np.array_equal(o[q, :n, 0], got["x"]) and np.array_equal(o[q, :n, 1], got["y"])
+                assert np.array_equal(o[q, :n, 2].view(np.float32), got["d"])
         if seed % 3 == 0:  # the batch entry point on the same shape: pair 1 swaps the images
             out, counts, nc, st = ctx.match_batch(np.stack([L, R]), np.stack([R, L]),
                                                   g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1), max(n, 1) * 2 + W * H)
