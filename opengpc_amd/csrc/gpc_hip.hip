@@ -156,6 +156,7 @@ struct gpc_hip_ctx {
   int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
   size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
+  int upload_mode = 1;            // GPC_HIP_UPLOAD: single-pair host path -- 0: hipMemcpyAsync per side, 1: one k_upload2 launch, 2: k_preprocess reads the host's pages
   int direct_max = 2;             // GPC_HIP_DIRECT_MAX: batches up to this size with a page-locked `out` are written by the
                                   // kernels straight into the caller's array (no packed records, no host expansion); 0 = never
   bool have_node_cpus = false;    // CPUs of the NUMA node this GPU hangs off (from sysfs), within the process's affinity mask
@@ -1311,6 +1312,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (ck && atoi(ck) > 0 && atoi(ck) <= 1024) c->chunk_pairs = atoi(ck);
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
   if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
+  if (const char* e = getenv("GPC_HIP_UPLOAD")) c->upload_mode = atoi(e);
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
   c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
@@ -1824,8 +1826,24 @@ static int match_batch_direct(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
   HIPCHK(c, hipHostGetDevicePointer((void**)&d_cnt, c->h_cnt, 0));
   uint8_t* d_l = (uint8_t*)c->raw.p;
   uint8_t* d_r = d_l + n * npairs;
-  HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
+  // Page-locked images are fetched by a kernel (one launch, both sides) instead of two copy-engine submissions; the
+  // byte count is a multiple of 16 (W is), the pointers must be 16-byte aligned (gpc_hip_host_alloc's are)
+  const void* vL = c->upload_mode ? device_view_of_host(rawL) : nullptr;
+  const void* vR = vL ? device_view_of_host(rawR) : nullptr;
+  const bool aligned = (((uintptr_t)vL | (uintptr_t)vR | (uintptr_t)d_l | (uintptr_t)d_r) & 15u) == 0 && (n * npairs) % 16 == 0 &&
+                       n * npairs / 16 < (1ull << 31);
+  if (vL && vR && aligned && c->upload_mode == 2) {  // the preprocess kernel reads the host's pages itself
+    d_l = (uint8_t*)vL;
+    d_r = (uint8_t*)vR;
+  } else if (vL && vR && aligned) {
+    const unsigned n16 = (unsigned)(n * npairs / 16);
+    hipLaunchKernelGGL(gpc::k_upload2, dim3((n16 + 255) / 256, 2), dim3(256), 0, c->stream, (const uint4*)vL, (const uint4*)vR,
+                       (uint4*)d_l, (uint4*)d_r, n16);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
+  }
   CHK(run_preprocess(c, d_l, d_r, W, H, npairs, 2, s->gradient_threshold));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false, (uint32_t*)c->codes.p));
   CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out_host, cap, d_cnt, d_cnt + npairs));

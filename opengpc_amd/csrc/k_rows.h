@@ -23,6 +23,17 @@ __device__ int block_prefix_rows(const int32_t* __restrict__ cnt, int first, int
   return s;
 }
 
+// Two page-locked host arrays (device views) -> device memory, 16 bytes per lane: the upload of the single-pair host
+// path.  One launch where two hipMemcpyAsync cost two copy-engine submissions (14 us each for 446 KB, 7-8 us apart).
+// n16: 16-byte words per array.  grid: (ceil(n16 / 256), 2)
+__global__ __launch_bounds__(256) void k_upload2(const uint4* __restrict__ src0, const uint4* __restrict__ src1,
+                                                 uint4* __restrict__ dst0, uint4* __restrict__ dst1, unsigned n16) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n16) return;
+  if (blockIdx.y == 0) dst0[i] = src0[i];
+  else dst1[i] = src1[i];
+}
+
 // totals[pair] = supports of the pair (sum of its row counts).  grid: (npairs)
 __global__ __launch_bounds__(RM_THREADS) void k_pair_totals(const int32_t* __restrict__ rowcnt, int H,
                                                            int32_t* __restrict__ totals) {

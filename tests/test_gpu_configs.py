@@ -260,6 +260,58 @@ def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
         ctx.close()
 
 
+def test_single_pair_host_path_with_page_locked_images(forest_paths):
+    """One or two pairs with a page-locked result array take the direct path of gpc_hip_match_batch: page-locked,
+    16-byte aligned IMAGES are fetched by one kernel launch (k_upload2), anything else by hipMemcpyAsync; GPC_HIP_UPLOAD=2
+    lets the preprocess kernel read the host's pages itself.  All of them against the device-resident entry point:
+    aligned and deliberately misaligned page-locked images, pageable ones, both knob settings."""
+    import torch
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    ctxs = []
+    try:
+        for mode in ("1", "2", "0"):
+            os.environ["GPC_HIP_UPLOAD"] = mode
+            try:
+                ctxs.append(g.Context(0))
+            finally:
+                del os.environ["GPC_HIP_UPLOAD"]
+        for (W, H, P, fo) in [(1024, 436, 1, "zero"), (272, 61, 2, "tau"), (48, 30, 1, "zero"), (528, 41, 2, "zero")]:
+            s = g.Settings.sparsematch()
+            Lh, Rh = synth_batch(W, H, [5 * i + 2 for i in range(P)])
+            cap = (W - 26) * (H - 26)
+            want = None
+            for ctx in ctxs:
+                ctx.load_forest(forest_paths[fo], W, H)
+                if want is None:
+                    d_L, d_R = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
+                    d_out = torch.zeros((P, cap, 3), dtype=torch.int32, device=dev)
+                    d_cnt = torch.zeros(P, dtype=torch.int32, device=dev)
+                    d_nc = torch.zeros((P, 2), dtype=torch.int32, device=dev)
+                    ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, P, s, d_out.data_ptr(), cap, d_cnt.data_ptr(), d_nc.data_ptr())
+                    ctx.synchronize()
+                    want = (d_cnt.cpu().numpy(), d_nc.cpu().numpy(), d_out.cpu().numpy())
+                    assert want[0].sum() > 0
+                n = Lh.size
+                flatL, flatR = ctx.pinned_empty((n + 16,), np.uint8), ctx.pinned_empty((n + 16,), np.uint8)
+                for off in (0, 1):  # offset 1: a page-locked image the 16-byte loads of the upload kernel cannot take
+                    Lp, Rp = flatL[off:off + n].reshape(Lh.shape), flatR[off:off + n].reshape(Rh.shape)
+                    Lp[:] = Lh
+                    Rp[:] = Rh
+                    for (a, b) in ((Lp, Rp), (Lp, Rh), (Lh, Rh)):
+                        out = ctx.pinned_empty((P, cap), g.SUPPORT_DTYPE)
+                        o, c2, n2, st = ctx.match_batch(a, b, s, cap, out=out)
+                        assert st == 0 and np.array_equal(c2, want[0]) and np.array_equal(n2, want[1])
+                        for i in range(P):
+                            k = int(c2[i])
+                            assert np.array_equal(o[i, :k]["x"], want[2][i, :k, 0]) and np.array_equal(o[i, :k]["y"], want[2][i, :k, 1])
+                            assert np.array_equal(o[i, :k]["d"], want[2][i, :k, 2].view(np.float32)), (W, H, off, i)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_packed_results_are_refused_outside_the_epipolar_sort_matcher(ctx, forest_paths):
     import torch
     import opengpc_amd as g

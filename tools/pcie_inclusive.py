@@ -92,7 +92,8 @@ def single_pair(ctx, W, H, s):
         first, rest = tt[0], sorted(tt[10:])
         res[kind] = {"ms_first_call": round(first * 1e3, 4), "ms_median": round(rest[len(rest) // 2] * 1e3, 4),
                      "ms_min": round(rest[0] * 1e3, 4), "Mpix_per_s": round(2.0 * W * H / rest[len(rest) // 2] / 1e6, 1),
-                     "supports": int(counts[0]), "status": int(st)}
+                     "supports": int(counts[0]), "status": int(st),
+                     "crc32": __import__("zlib").crc32(o[0, : int(counts[0])].tobytes())}
     res["timed_region"] = "one synchronous gpc_hip_match_batch call with one pair: host images -> host gpc_support array (sparsematch.cpp:45-52)"
     return res
 
