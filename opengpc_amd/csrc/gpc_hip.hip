@@ -182,6 +182,7 @@ struct gpc_hip_ctx {
   int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
   int gp_log2bins = 0;        // GPC_HIP_GP_LOG2BINS = 8 .. 11: force the number of code-range bins (A/B checks)
   int ht_hint_w = 0, ht_hint_h = 0, ht_hint_lbits = 0;  // what the hash-table planner ended on for the last image size: where it starts next time
+  int ht_mid = 0;             // GPC_HIP_HT_MID = 10 .. 64: force HtjArgs::mid (A/B checks; 10 = one wave per bucket beyond ten records)
   int ht_lbits = 0;           // GPC_HIP_HT_LBITS = 7 .. 10: force the buckets per bin of the hash-table matcher (A/B checks)
   int gp_target = 2000;       // GPC_HIP_GP_TARGET: records per side a partition of the non-epipolar matcher aims at. Per 32 pairs of
                               // 1024x436, join + gather: 1400 -> 208 us, 1800 -> 189, 2000 / 2200 -> 182, 2600 -> 192, 3000 -> 208
@@ -1081,7 +1082,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     int32_t* d_flag = bincnt + cnt_ints;
     {
       Timed t(c, KID_GLOBAL_KEYS);
-      HIPCHK(c, hipMemsetAsync(d_flag, 0, 2 * sizeof(int32_t), c->stream));
+      HIPCHK(c, hipMemsetAsync(d_flag, 0, 3 * sizeof(int32_t), c->stream));
       if (L.nbins > 1024)
         hipLaunchKernelGGL((gpc::k_gp_hist<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                            tabs, L, make_divw(W));
@@ -1097,7 +1098,7 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
                          (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * 4, d_flag);
       HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!c->h_flag[0]) {  // every bin fits the 4096-record kernel
       c->ht_hint_w = W;
@@ -1145,6 +1146,10 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     a.nbins = L.nbins;
     a.nchunk = L.nchunk;
     a.lbits = lbits;
+    // Ten-record lists that fill up (k_htjoin.h): measured per-record handling against one wave per bucket --
+    // 1920x1080 x8 (13 records per bucket): k_ht_join 787 -> 527 us; 1024x436 x32 (2.7 per bucket): 239 -> 278 us.  The
+    // batch's largest record count (k_ht_check reports it with the largest bin) decides: from 8 records per bucket on.
+    a.mid = c->ht_mid > 0 ? c->ht_mid : ((double)c->h_flag[2] / (double)HM_BUCKETS >= 8.0 ? 32 : HM_CAP);
     a.epi = L.epi;
     a.disp_high = s->disp_high;
     a.vtol = s->vertical_tolerance;
@@ -1295,6 +1300,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (const char* e = getenv("GPC_HIP_GP_LOG2BINS")) {
     const int v = atoi(e);
     if (v >= 8 && v <= 11) c->gp_log2bins = v;
+  }
+  if (const char* e = getenv("GPC_HIP_HT_MID")) {
+    const int v = atoi(e);
+    if (v >= HM_CAP && v <= 64) c->ht_mid = v;
   }
   if (const char* e = getenv("GPC_HIP_HT_LBITS")) {
     const int v = atoi(e);

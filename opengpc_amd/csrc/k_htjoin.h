@@ -43,6 +43,8 @@ struct HtjArgs {
   long recs;
   int nbins, nchunk, epi, disp_high, vtol, apply_filter;
   int lbits;               // log2(buckets per bin): HTJ_LBITS, or less for large images (then only the first threads own a bucket)
+  int mid;                 // buckets with 11 .. mid records keep one thread per record, fuller ones are taken by a wave each
+                           // (HM_CAP: every bucket with more than ten records goes to a wave -- the host's choice, see there)
   GpcDivW dw;
 };
 
@@ -94,6 +96,7 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
     if (nl + nr > cap) atomicOr(overflow, 1);
     atomicMax(overflow + 1, nl + nr);  // the batch's largest bin: the host sizes its next attempt by it
   }
+  if (threadIdx.x == 0) atomicMax(overflow + 2, NL + NR);  // the batch's largest pair: records per bucket (HtjArgs::mid)
 }
 
 // rank += (oy : oc : okv) < (y : c : kv) as 96-bit numbers, i.e. "state, then insertion order": a borrow chain.
@@ -119,9 +122,11 @@ __device__ __forceinline__ int htj_rank_add(int rank, uint32_t oy, uint32_t oc, 
 // bucket's ordered list (entries before it), moves there, publishes "equal state" / "other image" / "passes the
 // disparity filter" of the link (r, r + 1) as bits r, 10 + r, 20 + r of the bucket's word; the bucket's thread
 // replays OrderedLinkedList::getDuplicates on those bits and hands back the emitted links + their place.
-// Buckets with more than 10 records (repeated states: the zero code of a flat stretch of a row puts hundreds of
-// records into one bucket) are taken by one WAVE each instead: ten times the smallest kv above the last one (a
-// strided pass + a DPP minimum; insertion order = order of kv), the ten winners ranked among themselves.
+// Buckets with more than 10 records keep the first ten in insertion order (= order of kv).  Where they are the exception
+// (1024x436: 2.7 records per bucket; repeated states -- the zero code of a flat stretch of a row puts hundreds of records
+// into one bucket) one WAVE takes each: ten times the smallest kv above the last one (a strided pass + a DPP minimum),
+// the ten winners ranked among themselves.  Where they are the rule (1920x1080: 13 records per bucket) the buckets up
+// to HtjArgs::mid records stay with their records' threads (see "insert where a list fills up" below).
 // The kernel is bound by the number of LDS operations (random addresses, 32 waves per CU): a record is one 8-byte
 // LDS element, a bucket's start and count one word.
 // grid: (nbins, npairs); dynamic LDS: 8 * HTJ_THREADS * RPT bytes
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   __shared__ uint32_t s_bits[HTJ_BUCKETS];  // link bits, then emitted links | first output place << 10
   __shared__ uint32_t s_list[HTJ_CAP / (HM_CAP + 1) + 1];  // the buckets with more than 10 records
   __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_nbig;
+  __shared__ uint32_t s_nbig, s_nmid;
   const int bin = blockIdx.x, pair = blockIdx.y;
   const int tid = threadIdx.x;
   HJ_STAMP_INIT();
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   }
   s_cs[tid] = 0u;
   s_bits[tid] = 0u;
-  if (tid == 0) s_nbig = 0u;
+  if (tid == 0) s_nbig = s_nmid = 0u;
   HJ_STAMP(1);  // records arrive
   __syncthreads();
   int lb[HTJ_RPT], place[HTJ_RPT];
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
     uint32_t total;
     own_s = gp_block_exscan(own_cnt, s_w, &total);
     s_cs[tid] = own_s | (own_cnt << 16);
-    if (own_cnt > HM_CAP) s_list[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
+    if (own_cnt > (uint32_t)a.mid) s_list[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
+    else if (own_cnt > HM_CAP) s_nmid = 1u;  // (whoever writes, writes 1)
   }
   __syncthreads();
   HJ_STAMP(3);  // scan
@@ -212,14 +218,58 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
       const uint32_t w = s_cs[lb[j]];
       bs[j] = (int)(w & 0xFFFFu);
       htj_rec[bs[j] + place[j]] = make_uint2(code[j], kv[j]);
-      if ((w >> 16) > HM_CAP) lb[j] = -1;  // a wave takes that bucket
+      if ((w >> 16) > (uint32_t)a.mid) lb[j] = -1;  // a wave takes that bucket
       else len[j] = (int)(w >> 16);
     }
   }
   __syncthreads();
   HJ_STAMP(4);  // placed
 
-  // ---- OrderedLinkedList::insert of the buckets with more than 10 records: a full list drops the value
+  // ---- OrderedLinkedList::insert where a list fills up: a full list drops the value, so a bucket keeps the first ten
+  //      records in insertion order (= order of kv).  Buckets with 11 .. a.mid records (1920x1080: 13 records per
+  //      bucket on average, nearly every bucket) stay with their records' threads: a record counts the records of its
+  //      bucket inserted before it (len reads of 4 bytes, all of a step in flight together); the first ten then move
+  //      to the front of the bucket's stretch, the others drop out, and the bucket goes on as one of ten records.
+  //      (One wave per such bucket, as for the fuller ones below, was 43 % of the kernel at 1920x1080.)
+  const bool has_mid = s_nmid != 0u;  // block-uniform: bins without such a bucket skip the pass and its barriers
+  if (has_mid) {
+#pragma unroll
+    for (int j = 0; j < HTJ_RPT; ++j) place[j] = 0;  // (the arrival rank has been used)
+    // (no branch around a read: with one the compiler sinks the compare into the branch and waits for every read on the
+    // spot -- eight LDS round trips per step instead of one; a lane without an entry re-reads its bucket's first)
+    int maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < HTJ_RPT; ++j) maxlen = max(maxlen, len[j] > HM_CAP ? len[j] : 0);
+    maxlen = (int)wave_max_u32((uint32_t)maxlen);  // wave-uniform trip count
+#pragma unroll 1
+    for (int u = 0; u < maxlen; u += 2) {
+      uint32_t o0[HTJ_RPT], o1[HTJ_RPT];
+#pragma unroll
+      for (int j = 0; j < HTJ_RPT; ++j) {
+        const bool mid = len[j] > HM_CAP;
+        o0[j] = htj_rec[bs[j] + ((mid && u < len[j]) ? u : 0)].y;
+        o1[j] = htj_rec[bs[j] + ((mid && u + 1 < len[j]) ? u + 1 : 0)].y;
+      }
+#pragma unroll
+      for (int j = 0; j < HTJ_RPT; ++j) {
+        const bool mid = len[j] > HM_CAP;
+        place[j] += ((mid && u < len[j] && o0[j] < kv[j]) ? 1 : 0) + ((mid && u + 1 < len[j] && o1[j] < kv[j]) ? 1 : 0);
+      }
+    }
+    __syncthreads();  // every count is complete: the stretches may be rewritten
+#pragma unroll
+    for (int j = 0; j < HTJ_RPT; ++j)
+      if (len[j] > HM_CAP) {
+        if (place[j] < HM_CAP) {
+          htj_rec[bs[j] + place[j]] = make_uint2(code[j], kv[j]);
+          len[j] = HM_CAP;
+        } else {  // the list was full when this record came
+          lb[j] = -1;
+          len[j] = 0;
+        }
+      }
+  }
+  // ---- the buckets with more than a.mid records (repeated states; every bucket beyond ten where a.mid is ten), one wave each
   {
     const int lane = tid & 63, wave = tid >> 6;
     const int nbig = (int)s_nbig;  // block-uniform
@@ -288,6 +338,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
       }
     }
   }
+  if (has_mid) __syncthreads();  // the kept records of the 11 .. a.mid buckets are in place
   HJ_STAMP(5);  // 10-cap
   // ---- the other buckets: rank r = entries before this one, all of the thread's records side by side; a (wave, j)
   //      without entries left issues nothing
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   s_bits[tid] = emit | (base << 10);
   if (tid == 0) bincnt[bin] = (int32_t)total;
   uint2* st = a.staged + pair * (a.recs / 2) + ol;  // every pair has its own left record: at most nl of them
-  if (own_cnt > HM_CAP) {  // a wave's bucket: its thread writes the (few) pairs
+  if (own_cnt > (uint32_t)a.mid) {  // a wave's bucket: its thread writes the (few) pairs
     uint32_t pos = base;
     for (uint32_t todo = emit; todo; todo &= todo - 1u) {
       const int u = __builtin_ctz(todo);
