@@ -14,13 +14,13 @@
 //     the cheapest LDS read form on this chip for this pattern (profiles/r03_ubench2_issue_rates.txt: a test's taps +
 //     its 24 VALU take 8.7 ns per CU this way, 9.2-9.4 ns as aligned ds_read_b64 of row-interleaved storage, 11.4 ns as
 //     eight ds_read_b32).  64 lanes read 256 contiguous bytes: conflict-free;
-//   * the four unsigned byte compares of a test are done SWAR in 4 VALU ops (or, and, sub, v_bitop3) and shifted
-//     into byte planes exactly like the reference's out[0..3] registers (2 more: 6 ops per test and 4 pixels,
+//   * the four unsigned byte compares of a test are done SWAR in 2 VALU ops (v_not, v_lerp_u8: swar_ge below) and shifted
+//     into byte planes exactly like the reference's out[0..3] registers (2 more: 4 ops per test and 4 pixels,
 //     + 2 address adds per test); the planes are transposed into 4 codes with v_perm_b32 at the end;
 //   * the tests (packed LDS offsets, tau) are READ FROM DEVICE MEMORY with scalar loads, eight at a time (as a
 //     by-value kernel argument the 64 words stayed live in SGPRs for the whole kernel and the allocator spilled 59 of
 //     them); the test loop is fully unrolled, the taps of test t+1 are requested before test t is evaluated;
-//   * what bounds the kernel: during the tests LDS reads (2 dwords per test and 4 pixels) and the 6 VALU per test add
+//   * what bounds the kernel: during the tests LDS reads (2 dwords per test and 4 pixels) and the 4 VALU per test add
 //     up rather than overlap (52-56 % of a wave's time); the rest is waiting for the other waves at the two barriers
 //     per tile, staging, candidate flags and stores (profiles/r03_a_phase_stamps.txt).
 // No MFMA: this is gather/compare.
@@ -64,9 +64,17 @@ __device__ unsigned long long g_ht_stamps[16];
 
 // bit 7 of every byte: (b_byte >= a_byte), unsigned; the other bits are garbage
 __device__ __forceinline__ uint32_t swar_ge(uint32_t a, uint32_t b) {
+#ifdef HT_SWAR_SUB
   const uint32_t d = (b | SW_H) - (a & SW_M);  // per byte b_lo + 128 - a_lo: no borrow crosses bytes
   const uint32_t x = a ^ b;
-  return (x & b) | (~x & d);                   // top bits differ -> b's top bit decides (v_bfi_b32)
+  return (x & b) | (~x & d);                   // top bits differ -> b's top bit decides (v_bitop3_b32)
+#else
+  // v_lerp_u8 is a per-byte (x + y + (z & 1)) >> 1 with a 9-bit sum: (b + (255 - a) + 1) >> 1 = (b - a + 256) >> 1 has
+  // bit 7 set exactly when b >= a.  Two instructions (v_not, v_lerp_u8 -- the latter issues at 1.6 times the cost of a
+  // plain op, profiles/r03_ubench2_issue_rates.txt) where the subtract form takes four (or, and, sub, bitop3):
+  // k_hash 432 -> 412-417 us per 256 pairs on one box.
+  return __builtin_amdgcn_lerp(b, ~a, 0x01010101u);
+#endif
 }
 
 // _mm_subs_epi8(b, tau) on 4 packed bytes: signed saturating subtract (filter.hpp:649-651).

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, unsigned long long
     else if (MODE == 11) { REP8(OP3("v_fma_f32")) }
     else if (MODE == 12) { REP8(OPS("v_add_u32_sdwa", "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")) }
     else if (MODE == 13) { REP8(OPS("v_add_u32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")) }
+    else if (MODE == 17) { REP8(OP3("v_lerp_u8")) }
+    else if (MODE == 18) { REP8(OP3("v_lshl_add_u32")) }
+    else if (MODE == 19) { REP8(OP3("v_sad_u8")) }
+    else if (MODE == 40) { REP8(OP3("v_add3_u32")) }
+    else if (MODE == 41) { REP8(OP3("v_xad_u32")) }
+    else if (MODE == 42) { REP8(OP3("v_msad_u8")) }
     else if (MODE == 14) {
       REP8(asm volatile("v_bitop3_b32 %0, %8, %0, %9 bitop3:0xd8\n\tv_bitop3_b32 %1, %8, %1, %9 bitop3:0xd8\n\t"
                         "v_bitop3_b32 %2, %8, %2, %9 bitop3:0xd8\n\tv_bitop3_b32 %3, %8, %3, %9 bitop3:0xd8\n\t"
@@ -229,6 +235,7 @@ int main() {
     {"v_add_u32", 0, 64}, {"v_and_b32", 1, 64}, {"v_xor_b32", 2, 64}, {"v_sub_u32", 3, 64}, {"v_lshrrev_b32", 4, 64},
     {"v_bfi_b32", 5, 64}, {"v_perm_b32", 6, 64}, {"v_alignbyte_b32", 7, 64}, {"v_and_or_b32", 8, 64}, {"v_lshl_or_b32", 9, 64},
     {"v_pk_sub_u16", 10, 64}, {"v_fma_f32", 11, 64}, {"v_add_u32_sdwa", 12, 64}, {"v_add_u32_dpp", 13, 64}, {"v_bitop3_b32", 14, 64},
+    {"v_lerp_u8", 17, 64}, {"v_lshl_add_u32", 18, 64}, {"v_sad_u8", 19, 64}, {"v_add3_u32", 40, 64}, {"v_xad_u32", 41, 64}, {"v_msad_u8", 42, 64},
     {"v_cmp+v_addc (pairs)", 15, 64}, {"swar test mix (8 valu)", 16, 64},
     {"ds_read_b32 linear", 20, 64}, {"ds_read_b64 linear", 21, 64}, {"ds_read_b128 linear", 22, 64}, {"ds_read_u8 linear", 23, 64},
     {"2 ds_read_b32 + 6 valu", 24, 64}, {"ds_read_b64 addr%8==4", 25, 64}, {"ds_read_b128 addr%16==4", 26, 64},
@@ -244,7 +251,7 @@ int main() {
       Res r;
       switch (c.mode) {
 #define RUN(M) case M: r = run<M>(d_out, d_cyc, blocks, iters); break;
-        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16)
+        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(40) RUN(41) RUN(42)
         RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35)
         default: continue;
       }
