@@ -36,6 +36,8 @@
 struct GpcForestDev {
   int32_t off[32];    // LDS DWORD offsets of a test's two taps, packed (off_a & 0xFFFF) | (off_b << 16);
                       // byte offset = (dx & 3) * HT_COPY + dy * HT_STRIDE + (dx - (dx & 3))
+  int32_t boff[64];   // the same as BYTE offsets, tap a of test t in [2t], tap b in [2t+1] (k_hash.h, HT_BYTE_OFFS: one plain add
+                      // per tap address instead of shift + mask + shift-add)
   int32_t tau[32];    // (int8_t) tau, sign-extended (SSE arithmetic) / the int as given (Naive arithmetic)
   int32_t num_tests;
   int32_t type;

@@ -1511,11 +1511,15 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
       offs[q] = (sft * HT_COPY + dy * HT_STRIDE + (dx - sft)) / 4;
     }
     f.off[t] = (offs[0] & 0xFFFF) | (offs[1] << 16);
+    f.boff[2 * t] = offs[0] * 4;
+    f.boff[2 * t + 1] = offs[1] * 4;
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
     f.tau8[t >> 2] |= (int32_t)((uint32_t)(fm->tau[t] & 0xFF) << ((t & 3) * 8));
     // gpcFilterNaive shifts the code left per test: test t ends on bit T-1-t (filter.hpp:245-249)
     const int u = fm->num_tests - 1 - t;
     fn.off[u] = f.off[t];
+    fn.boff[2 * u] = f.boff[2 * t];
+    fn.boff[2 * u + 1] = f.boff[2 * t + 1];
     fn.tau[u] = fm->tau[t];              // gpcFilterTauNaive uses the int as is (:276)
   }
   f.num_tests = fn.num_tests = fm->num_tests;

@@ -165,9 +165,14 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
   uint32_t a[D][RPW], b[D][RPW];
   const uint32_t* base = reinterpret_cast<const uint32_t*>(tile + lanebase);
   auto load = [&](int i, int slot) {
+#ifndef HT_PACKED_OFFS  // (byte offsets, two words per test: 404-405 vs 408-414 us per 256 pairs against the packed dword offsets)
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + fp->boff[2 * (t0 + i)]);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + fp->boff[2 * (t0 + i) + 1]);
+#else
     const int packed = fp->off[t0 + i];
     const uint32_t* pa = base + (int)(int16_t)(packed & 0xFFFF);
     const uint32_t* pb = base + (packed >> 16);
+#endif
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       a[slot][r] = pa[r * (HT_STRIDE / 4)];
