@@ -547,13 +547,16 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
   // tiles cover the candidate rows 13 .. H-14 only (k_hash.h)
   const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H - 2 * GPC_R + HT_Y - 1) / HT_Y;
+#ifndef HT_SLOTS
+#define HT_SLOTS 512   // workgroups of k_hash the device holds at once (2 per CU: 67 KiB of LDS each)
+#endif
   int tpw = 1;
-  if ((long)gx * tiles_y * nimg >= 2 * 512) {  // small launches keep one tile per workgroup (parallelism first)
+  if ((long)gx * tiles_y * nimg >= 2 * HT_SLOTS) {  // small launches keep one tile per workgroup (parallelism first)
     double best = 1e30;
     for (int t = 2; t <= 16 && t <= tiles_y; ++t) {
       const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
-      if (nwg < 512) break;
-      const long slots = (nwg + 511) / 512 * 512;
+      if (nwg < HT_SLOTS) break;
+      const long slots = (nwg + HT_SLOTS - 1) / HT_SLOTS * HT_SLOTS;
       const double score = (double)(slots - nwg) / (double)slots + ((tiles_y % t) ? 0.04 : 0.0);  // idle tail + ragged split
       if (score < best - 1e-9) { best = score; tpw = t; }
     }

@@ -227,8 +227,13 @@ __device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & SW_
 // The tests are read from memory (fp, 264 bytes every wave shares) with scalar loads, eight at a time: as
 // a by-value kernel argument the 64 words stayed live in SGPRs for the whole kernel and the allocator spilled
 // 59 of them to VGPR lanes (~100 v_readlane / v_writelane per tile).
+#ifdef HT_WAVES_PER_EU   // tuning builds: a register budget for more workgroups per CU than the launch bounds alone give
+#define HT_OCC __attribute__((amdgpu_waves_per_eu(HT_WAVES_PER_EU, HT_WAVES_PER_EU)))
+#else
+#define HT_OCC
+#endif
 template <bool TAU, bool DENSE, bool NAIVE>
-__global__ __launch_bounds__(HT_THREADS) void k_hash(const uint8_t* __restrict__ smooth,
+__global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
