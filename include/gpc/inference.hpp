@@ -85,7 +85,24 @@ struct ContextHolder {
   gpc_filter_mask uploaded;
   bool have = false;
   size_t support_hint = 0;  // supports of this thread's last matchPair call (+ slack): how large the next result array starts
+  // matchPair's page-locked staging: the two images go in and the supports come out through memory the device reads and
+  // writes directly (ndb::Buffer and std::vector are pageable: the runtime would stage every copy itself, synchronously)
+  void* pin_in = nullptr;
+  void* pin_out = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0;
+  bool pinned(void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return true;
+    if (*p) gpc_hip_host_free(ctx, *p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4;
+    if (gpc_hip_host_alloc(ctx, want, p) != GPC_OK) return false;
+    *cap = want;
+    return true;
+  }
   ~ContextHolder() {
+    if (ctx && pin_in) gpc_hip_host_free(ctx, pin_in);
+    if (ctx && pin_out) gpc_hip_host_free(ctx, pin_out);
     if (ctx) gpc_hip_destroy(ctx);
   }
 };
@@ -235,29 +252,41 @@ class Forest {
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
-    // The array is value-initialised element by element (std::vector) before the library fills it: sized by the last
-    // call's count rather than by the worst case (one support per pixel), and never so small that a textured pair needs
-    // the call twice (the second attempt below; W*H/2 records were too few for the 1024x436 test pair and doubled its time).
-    const size_t worst = (size_t)simg.rows() * simg.cols();
-    size_t cap0 = h.support_hint ? h.support_hint : worst * 3 / 4 + 1;
-    if (cap0 > worst + 1) cap0 = worst + 1;
-    std::vector<ndb::Support> supp(cap0);
+    // Images and supports pass through page-locked staging memory of this thread's context (one memcpy each way on the
+    // host; the kernels read the images and write the 12-byte supports over the link themselves: the single-pair path of
+    // gpc_hip_match_batch).  The staging array is sized by the last call's count rather than by the worst case (one
+    // support per pixel), and never so small that a textured pair needs the call twice (the second attempt below).
+    const size_t npix = (size_t)simg.rows() * simg.cols();
+    size_t cap0 = h.support_hint ? h.support_hint : npix * 3 / 4 + 1;
+    if (cap0 > npix + 1) cap0 = npix + 1;
+    const size_t in_bytes = (npix + 15) / 16 * 16;  // the second image starts 16-byte aligned
+    if (!h.pinned(&h.pin_in, &h.pin_in_cap, 2 * in_bytes) || !h.pinned(&h.pin_out, &h.pin_out_cap, cap0 * sizeof(gpc_support))) {
+      detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
+      return std::vector<ndb::Support>();
+    }
+    uint8_t* pl = static_cast<uint8_t*>(h.pin_in);
+    uint8_t* pr = pl + in_bytes;
+    memcpy(pl, simg.data(), npix);
+    memcpy(pr, timg.data(), npix);
     int n = 0;
-    int st = gpc_hip_match_pair(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s,
-                                reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
-                                candidatesR);
+    int st = gpc_hip_match_pair(h.ctx, pl, pr, simg.cols(), simg.rows(), &s, static_cast<gpc_support*>(h.pin_out), (int)cap0, &n,
+                                candidatesL, candidatesR);
     if (st == GPC_E_CAPACITY) {
-      supp.resize((size_t)n + 1);
-      st = gpc_hip_match_pair(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s,
-                              reinterpret_cast<gpc_support*>(supp.data()), (int)supp.size(), &n, candidatesL,
-                              candidatesR);
+      cap0 = (size_t)n + 1;
+      if (!h.pinned(&h.pin_out, &h.pin_out_cap, cap0 * sizeof(gpc_support))) {
+        detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
+        return std::vector<ndb::Support>();
+      }
+      st = gpc_hip_match_pair(h.ctx, pl, pr, simg.cols(), simg.rows(), &s, static_cast<gpc_support*>(h.pin_out), (int)cap0, &n,
+                              candidatesL, candidatesR);
     }
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_match_pair");
       return std::vector<ndb::Support>();
     }
+    const ndb::Support* res = static_cast<const ndb::Support*>(h.pin_out);
+    std::vector<ndb::Support> supp(res, res + n);  // (one copy; no element-by-element value-initialisation first)
     h.support_hint = (size_t)n + (size_t)n / 8 + 1024;
-    supp.resize(n);
     return supp;
   }
 
