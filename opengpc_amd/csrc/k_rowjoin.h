@@ -501,6 +501,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     fetch_row(y);
   }
   RJ_STAMP_INIT();
+#ifdef RJ_DBG_PADVALU  // calibration: how much of a row's time is VALU issue?  RJ_DBG_PADVALU x 8 dependent-free adds per wave and row
+  {
+    uint32_t p0 = tid, p1 = tid + 1, p2 = tid + 2, p3 = tid + 3;
+    for (int q = 0; q < RJ_DBG_PADVALU; ++q)
+      asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, %2, %3\n\tv_add_u32 %3, %3, %0\n\t"
+                   "v_add_u32 %0, %0, %2\n\tv_add_u32 %1, %1, %3\n\tv_add_u32 %2, %2, %0\n\tv_add_u32 %3, %3, %1"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+    if ((p0 ^ p1 ^ p2 ^ p3) == 0x12345u && W < 0) rj_lds[0] = p0;  // (keeps the adds)
+  }
+#endif
+#ifdef RJ_DBG_PADSALU
+  {
+    uint32_t q0 = (uint32_t)W, q1 = (uint32_t)H;
+    for (int q = 0; q < RJ_DBG_PADSALU; ++q)
+      asm volatile("s_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, %0\n\t"
+                   "s_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, %0"
+                   : "+s"(q0), "+s"(q1) : : "scc");
+    if ((q0 ^ q1) == 0x12345u && W < 0) rj_lds[0] = q0;
+  }
+#endif
   // ---- 0. this row's codes (already in flight), table clear, next row's loads
   uint32_t kl[SPT], kr[SPT];  // (the code itself is kl - 1 wherever it is needed: one register per slot less)
   uint32_t spl = 0u, spr = 0u;
