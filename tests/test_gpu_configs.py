@@ -461,6 +461,43 @@ def test_large_images_in_the_device_wide_modes(ctx, forest_paths):
             assert np.array_equal(got, want.astype(got.dtype))
 
 
+def test_hash_table_lists_that_fill_up_per_record_and_per_wave(forest_paths):
+    """ndb::Hashmatch keeps the first ten elements of a bucket.  k_ht_join handles a bucket with more records either with
+    one wave per bucket or -- where such buckets are the rule, by the batch's records per bucket -- with one thread per
+    record (HtjArgs::mid).  GPC_HIP_HT_MID forces the threshold: 10 (always a wave), 12 and 32 (per record up to there) on
+    a textured 1280x720 pair (8.5 records per bucket), a small pair and striped images whose few states put hundreds of
+    records into one bucket; all against the oracle, both row conventions."""
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_pair
+    from oracle.pyoracle import Oracle
+    fast = Oracle(fast=True)
+    ctxs = []
+    try:
+        for mid in ("10", "12", "32"):
+            os.environ["GPC_HIP_HT_MID"] = mid
+            try:
+                ctxs.append(g.Context(0))
+            finally:
+                del os.environ["GPC_HIP_HT_MID"]
+        cases = [("tau",) + synth_pair(1280, 720, 2, 25), ("zero",) + synth_pair(528, 200, 4, 12)]
+        stripes = np.tile((np.arange(1024) // 5 * 53 % 256).astype(np.uint8), (300, 1))
+        stripes[::7] = np.roll(stripes[::7], 3, axis=1)
+        cases.append(("zero", stripes, np.roll(stripes, 9, axis=1)))
+        for fo, L, R in cases:
+            H, W = L.shape
+            rc, f = fast.read_forest(forest_paths[fo], W, H)
+            for epi in (True, False):
+                want, nl, nr = fast.match_pair(L, R, f, sparsematch_settings(5, 128, 1, epi, True))
+                for ctx in ctxs:
+                    ctx.load_forest(forest_paths[fo], W, H)
+                    got, n, ncand, st = ctx.match_pair(L, R, g.Settings(5, 128, 1, epi, True, 1))
+                    assert st == 0 and (nl, nr) == ncand and n == len(want)
+                    assert np.array_equal(got, want.astype(got.dtype)), (fo, W, H, epi)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_4k_pair_in_the_device_wide_modes(ctx, forest_paths):
     """3840x2160 (BASELINE configs[4]'s size) with epipolarMode off and with the hash table: beyond ~6.5 M pixels the
     partition plan used to ask for more LDS than a workgroup has (8 bytes per POSSIBLE partition) and the call failed
