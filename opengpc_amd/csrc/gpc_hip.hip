@@ -899,7 +899,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
   const size_t plan_bytes = sizeof(int32_t) * ((size_t)L.ps * npairs + 4);
   CHK(ensure(c, c->gpart, sizeof(int32_t) * tab_ints + plan_bytes));
-  CHK(ensure(c, c->staged, sizeof(uint32_t) * (size_t)(g.nmax / 2) * npairs));
+  CHK(ensure(c, c->staged, sizeof(uint2) * (size_t)(g.nmax / 2) * npairs));  // (left, right) pixel index per match
   if (!c->h_flag) HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
   int32_t* tabs = (int32_t*)c->gpart.p;
   int32_t* part = tabs + tab_ints;

@@ -90,11 +90,17 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
   const int32_t* tl = tabs + (long)(pair * 2) * nbins * nchunk;
   const int32_t* tr = tl + (long)nbins * nchunk;
   const int NL = stats[(pair * 2) * GPC_STAT_STRIDE + GPC_STAT_NCAND], NR = stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+  int mx = 0;
   for (int bin = threadIdx.x; bin < nbins; bin += blockDim.x) {
     const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
     const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
-    if (nl + nr > cap) atomicOr(overflow, 1);
-    atomicMax(overflow + 1, nl + nr);  // the batch's largest bin: the host sizes its next attempt by it
+    mx = max(mx, nl + nr);
+  }
+  // (one atomic per wave: one per bin on a single word took 19 us per batch of 8 at 1678 bins)
+  mx = (int)wave_max_u32((uint32_t)mx);
+  if ((threadIdx.x & 63) == 0) {
+    if (mx > cap) atomicOr(overflow, 1);
+    atomicMax(overflow + 1, mx);  // the batch's largest bin: the host sizes its next attempt by it
   }
   if (threadIdx.x == 0) atomicMax(overflow + 2, NL + NR);  // the batch's largest pair: records per bucket (HtjArgs::mid)
 }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
   }
 }
 
-// Matches of the partitions (staged by the join as positions xvL | xvR << 16 inside the partition) -> the caller's
+// Matches of the partitions (staged by the join as the two pixel indices) -> the caller's
 // array in partition order.  grid: (ceil(pmax / GPG_PARTS), npairs)
 #define GPG_PARTS 2
 __global__ __launch_bounds__(RM_THREADS) void k_gp_gather(const uint32_t* __restrict__ staged, const int32_t* __restrict__ part,
@@ -363,17 +363,15 @@ __global__ __launch_bounds__(RM_THREADS) void k_gp_gather(const uint32_t* __rest
   const int32_t* rc = blk + g.o_rowcnt;
   int off = block_prefix_rows(rc, 0, min(p0, nparts));
   const int pend = min(p0 + GPG_PARTS, nparts);
-  const uint32_t* vl = vals + pair * recs;
-  const uint32_t* vr = vl + recs / 2;
-  const uint32_t* st = staged + pair * (recs / 2);
+  const uint2* st = reinterpret_cast<const uint2*>(staged) + pair * (recs / 2);
   char* o = reinterpret_cast<char*>(out) + pair * out_stride_bytes;
   for (int p = p0; p < pend; ++p) {
-    const int cnt = rc[p], ol = blk[g.o_off + p], orr = blk[g.o_off + g.pmax + 1 + p];
+    const int cnt = rc[p], ol = blk[g.o_off + p];
     for (int i = threadIdx.x; i < cnt; i += RM_THREADS) {
       const int pos = off + i;
       if (pos >= cap) break;
-      const uint32_t v = st[ol + i];
-      const uint32_t kl = vl[ol + (v & 0xFFFFu)], kr = vr[orr + (v >> 16)];
+      const uint2 v = st[ol + i];
+      const uint32_t kl = v.x, kr = v.y;
       const int yl = divw(kl, wd), yr = divw(kr, wd);
       const int xl = (int)kl - yl * wd.W, xr = (int)kr - yr * wd.W;
       if (mode == 0) {

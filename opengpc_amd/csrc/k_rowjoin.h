@@ -157,7 +157,7 @@ struct RjVirt {
   const uint32_t* keys;   // [npairs][recs]: side s of a pair at + s * (recs / 2)
   const uint32_t* vals;   // pixel index y * W + x of the record
   int32_t* part;          // per pair (stride ps ints): cursors, partition offsets, match counts, misc (GpLayout)
-  uint32_t* staged;       // [npairs][recs / 2]  (xvL | xvR << 16) of a partition's matches at its left offset
+  uint32_t* staged;       // [npairs][recs / 2] uint2: (left, right) pixel index of a partition's matches at its left offset
   long recs, ps;
   int o_off, o_rowcnt, o_misc, pmax;
   GpcDivW dw;
@@ -843,7 +843,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (uint32_t i = s0; i < e0; ++i) rank += (r_key[i] < cj);
       }
-      dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
+      if (VIRT) {
+        // the two PIXEL INDICES, not the positions inside the partition: the partition's records were read by this
+        // workgroup a moment ago (L2), where k_gp_gather fetched the same two words per match at random from memory
+        // (83 -> 4x us per 8 pairs of 1920x1080 for that kernel)
+        uint2* d2 = reinterpret_cast<uint2*>(v.staged) + pair * (v.recs / 2) + v_offl;
+        d2[rank] = make_uint2(vvl[j * NT + tid], vvr[xr[j]]);
+      } else {
+        dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
+      }
     }
   if (!FUSE && tid == 0) {
     if (VIRT) vblk[v.o_rowcnt + y] = (int32_t)r_cnt[NB];
