@@ -147,6 +147,8 @@ struct gpc_hip_ctx {
   hipStream_t stream = nullptr;
   // gpc_hip_match_batch: upload / download streams and the events that chain a chunk's stages
   hipStream_t s_in = nullptr, s_out = nullptr, s_cnt = nullptr;
+  hipStream_t s_aux = nullptr;            // the non-epipolar matcher's launch for over-large partitions runs beside the main one
+  hipEvent_t e_fork = nullptr, e_join = nullptr;
   hipEvent_t e_in[4] = {}, e_comp[4] = {}, e_cnt[4] = {}, e_out[4] = {};
   DevBuf packed;                  // packed results of the chunks in flight (3 slots)
   void* h_stage = nullptr;        // page-locked landing area of packed results (4 slots)
@@ -895,7 +897,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   L.o_off = 0;
   L.o_rowcnt = L.o_off + 2 * (L.pmax + 1);
   L.o_misc = L.o_rowcnt + L.pmax;
-  L.ps = L.o_misc + 8;
+  L.ps = L.o_misc + 8 + GP_BIGCAP;
   const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
   const size_t plan_bytes = sizeof(int32_t) * ((size_t)L.ps * npairs + 4);
   CHK(ensure(c, c->gpart, sizeof(int32_t) * tab_ints + plan_bytes));
@@ -929,7 +931,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
                        (const int32_t*)c->stats.p, part, L, d_flag);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->h_flag[0]) return GPC_OK;  // a single bin beyond 8192 records: the caller sorts instead
   const bool big_bins = c->h_flag[2] > GP_NB;  // some partitions (single bins) need the 8192-record join
@@ -963,6 +965,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     v.dw = make_divw(W);
     v.vtol = s->vertical_tolerance;
     v.min_recs = -1;
+    v.use_list = 0;
     // 8192 slots for up to 4096 left records: 64 KiB, two workgroups = 32 waves per CU; 16384 for up to 8192: one workgroup.
     // Every partition goes to the 4096-record launch except the bins that are larger by themselves: those few (19 of
     // 1024 code ranges of a 1920x1080 image with the Tau forest) get a launch of the 8192-record instantiation, in which
@@ -972,21 +975,42 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     size_t lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
     const int apply_filter = (mode == 0);
     const dim3 jgrid(maxparts, npairs);
-#define LAUNCH_VJOIN(SPT, WIDE)                                                                                         \
+    dim3 jgrid_(jgrid);
+#define LAUNCH_VJOIN(SPT, WIDE, STREAM)                                                                                 \
   do {                                                                                                                  \
     const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, 1024, WIDE, true>);                            \
     CHK(allow_dyn_lds(c, fn_, lds));                                                                                    \
-    hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid, dim3(1024), lds, c->stream, (const uint32_t*)nullptr, \
+    hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid_, dim3(1024), lds, STREAM, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
                        (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v, gpc::RjFuse());                              \
   } while (0)
-    if (wide) LAUNCH_VJOIN(4, true); else LAUNCH_VJOIN(4, false);
     if (big_bins) {
+      // The few over-large partitions first, on a stream of their own: their 8192-record workgroups (one per CU, 44-48 us
+      // per 8 pairs of 1920x1080 as a launch by itself) run beside the 4096-record launch instead of after it.
+      if (!c->s_aux) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
+      }
+      HIPCHK(c, hipEventRecord(c->e_fork, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->s_aux, c->e_fork, 0));
+      gpc::RjVirt v4 = v;
       v.min_recs = GP_NB;
+      if (c->h_flag[3] <= GP_BIGCAP) {  // the plan's work list is the grid
+        v.use_list = 1;
+        jgrid_ = dim3(c->h_flag[3] > 0 ? c->h_flag[3] : 1, npairs);
+      }
       log2s = 14;
       lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
-      if (wide) LAUNCH_VJOIN(8, true); else LAUNCH_VJOIN(8, false);
+      if (wide) LAUNCH_VJOIN(8, true, c->s_aux); else LAUNCH_VJOIN(8, false, c->s_aux);
+      HIPCHK(c, hipEventRecord(c->e_join, c->s_aux));
+      v = v4;
+      jgrid_ = jgrid;
+      log2s = 13;
+      lds = ((size_t)8 * ((1u << log2s) + 1) + 15) / 16 * 16;
     }
+    if (wide) LAUNCH_VJOIN(4, true, c->stream); else LAUNCH_VJOIN(4, false, c->stream);
+    if (big_bins) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_join, 0));
 #undef LAUNCH_VJOIN
     hipLaunchKernelGGL(gpc::k_gp_gather, dim3((maxparts + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
                        (const uint32_t*)c->staged.p, (const int32_t*)part, L, (const uint32_t*)vals, g.bs.recs, make_divw(W),
@@ -1369,6 +1393,11 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
       (void)hipEventDestroy(c->e_cnt[i]);
       (void)hipEventDestroy(c->e_out[i]);
     }
+  }
+  if (c->s_aux) {
+    (void)hipStreamDestroy(c->s_aux);
+    (void)hipEventDestroy(c->e_fork);
+    (void)hipEventDestroy(c->e_join);
   }
   c->pool.stop();
   if (c->h_stage) (void)hipHostFree(c->h_stage);

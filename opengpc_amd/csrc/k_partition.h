@@ -45,9 +45,10 @@ namespace gpc {
 // tabs: [npairs * 2][nbins * nchunk] int32 -- records per (bin, chunk of rows) of one image, bin-major; after the
 //       exclusive scan (k_g_scan) entry (b, c) is where chunk c's records of bin b start in the image's record array.
 // plan: per-pair block of int32 (stride ps): [off L : pmax + 1][off R : pmax + 1][rowcnt : pmax][misc : 8]
-// misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records
+// misc: 0 number of partitions, 1 overflow flag, 2 last partition with right records, 3 number of over-large partitions,
+//       8 .. 8 + GP_BIGCAP - 1 their numbers
 // batch words (after the plan blocks): [0] some pair overflowed, [1] largest number of partitions of a pair,
-//                                       [2] largest bin (records of one side)
+//                                       [2] largest bin (records of one side), [3] largest list of over-large partitions
 struct GpLayout {
   int nbins, bshift, nchunk, rows_per_chunk, pmax, target;
   int cap;                       // records per side a partition aims to stay below: bins larger than cap - target stand alone
@@ -66,6 +67,8 @@ __device__ __forceinline__ uint32_t gp_bin(uint32_t code, int y, const GpLayout&
 #define GP_NPARTS 0
 #define GP_OVERFLOW 1
 #define GP_LASTR 2
+#define GP_NBIG 3         // partitions with more than GP_NB records on a side (single bins): listed at misc + 8
+#define GP_BIGCAP 248     // entries of that list (more of them: the second launch covers the whole grid again)
 
 // No global atomics anywhere (scattered ones run at ~20 G/s on MI355X: 18 M records took 0.76 ms to count and 1.5 ms to
 // place that way): a workgroup counts the records of its chunk of rows per bin in LDS, the table is scanned, and the
@@ -211,6 +214,10 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
         const int nl = s_off[p + 1] - s_off[p], nr = s_off[g.pmax + 1 + p + 1] - s_off[g.pmax + 1 + p];
         if (nl > g.cap_hard || nr > g.cap_hard) over = 1;
         if (nr > 0) last_r = p;
+        if (nl > GP_NB || nr > GP_NB) {  // the 8192-record join's work list
+          const int at = atomicAdd(&misc[GP_NBIG], 1);
+          if (at < GP_BIGCAP) misc[8 + at] = p;
+        }
       }
     }
   }
@@ -220,9 +227,11 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
   }
   for (int o = 32; o > 0; o >>= 1) last_r = max(last_r, __shfl_xor(last_r, o));
   if ((tid & 63) == 0 && last_r >= 0) atomicMax(&misc[GP_LASTR], last_r);
+  __syncthreads();  // the list's length is final
   if (tid == 0) {
     misc[GP_NPARTS] = too_many ? 0 : (int32_t)nparts;
     if (!too_many) atomicMax(batch_overflow + 1, (int32_t)nparts);  // the batch's largest partition count: the join's grid
+    atomicMax(batch_overflow + 3, misc[GP_NBIG]);                    // ... and the largest work list of over-large partitions
   }
 }
 

@@ -162,6 +162,9 @@ struct RjVirt {
   int o_off, o_rowcnt, o_misc, pmax;
   GpcDivW dw;
   int vtol;
+  int use_list;           // 1: workgroup b takes partition part[o_misc + 8 + b] (the plan's list of over-large partitions: the grid
+                          // of the 8192-record launch is that list, not every partition of which nearly all return at once --
+                          // dispatching ~8000 workgroups of 128 KiB of LDS each cost 44-48 us per 8 pairs of 1920x1080)
   int min_recs;           // this launch takes the partitions with more than min_recs records on a side (and at most NT*SPT):
                           // the few bins that are large by themselves go to the 8192-slot instantiation, the rest to the 4096 one
 };
@@ -386,10 +389,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   // VIRT: this workgroup's partition
   int32_t* vblk = nullptr;
   const uint32_t *vkl = nullptr, *vkr = nullptr, *vvl = nullptr, *vvr = nullptr;
-  int v_nl = 0, v_nr = 0, v_offl = 0;
+  int v_nl = 0, v_nr = 0, v_offl = 0, v_p = 0;
   if (VIRT) {
     vblk = v.part + pair * v.ps;
-    const int p = blockIdx.x;
+    int p = blockIdx.x;
+    if (v.use_list) {
+      if (p >= vblk[v.o_misc + 3]) return;  // GP_NBIG
+      p = vblk[v.o_misc + 8 + p];
+    }
+    v_p = p;
     if (p >= vblk[v.o_misc + 0]) return;  // GP_NPARTS
     v_offl = vblk[v.o_off + p];
     const int offr = vblk[v.o_off + v.pmax + 1 + p];
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
 
   // A workgroup handles `rpw` consecutive rows; the NEXT row's codes are fetched into registers
   // while the current row is joined, so only the first row's load latency is exposed.
-  const int row0 = VIRT ? (int)blockIdx.x : GPC_R + blockIdx.x * rpw;
+  const int row0 = VIRT ? v_p : GPC_R + blockIdx.x * rpw;
   uint32_t ncl[SPT], ncr[SPT];
   uint32_t nspl = 0u, nspr = 0u;  // WIDE: bit j = pixel slot j is a candidate whose code is 0xFFFFFFFF
   auto fetch_row = [&](int yy) {
