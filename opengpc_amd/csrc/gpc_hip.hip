@@ -177,6 +177,7 @@ struct gpc_hip_ctx {
 
   // workspaces
   DevBuf raw, smooth, grad, candmap, codes, staged, rowcnt, stats, out, counts, ncand, mask;
+  DevBuf gkv;  // records (code, pixel index) of the partitioned device-wide matchers, by bin
   DevBuf gkeys[2], gvals[2], ghist, gmisc, hkeys[2], hvals[2], hrec;
   DevBuf gpart;       // partition plan of the non-epipolar matcher (k_partition.h) + one overflow word for the batch
   int32_t* h_flag = nullptr;  // page-locked landing word of that overflow flag
@@ -908,8 +909,8 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
   int32_t* d_flag = part + (size_t)L.ps * npairs;
   const uint32_t* codes = (const uint32_t*)c->codes.p;
   const uint8_t* wcand = wide ? d_cand : nullptr;
-  uint32_t* keys = (uint32_t*)c->gkeys[0].p;
-  uint32_t* vals = (uint32_t*)c->gvals[0].p;
+  CHK(ensure(c, c->gkv, sizeof(uint2) * (size_t)g.bs.recs * npairs));
+  uint2* kv = (uint2*)c->gkv.p;
   dim3 cgrid(L.nchunk, 2, npairs);
   const size_t plan_lds = sizeof(int32_t) * 2 * ((size_t)L.pmax + 1);
   {
@@ -940,20 +941,19 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     Timed t(c, KID_GLOBAL_SORT);
     if (L.nbins > 1024)
       hipLaunchKernelGGL((gpc::k_gp_scatter<false, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     else if (L.nbins > 256)
       hipLaunchKernelGGL((gpc::k_gp_scatter<false, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     else
       hipLaunchKernelGGL((gpc::k_gp_scatter<false, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
     gpc::RjVirt v;
-    v.keys = keys;
-    v.vals = vals;
+    v.kv = kv;
     v.part = part;
     v.staged = (uint32_t*)c->staged.p;
     v.recs = g.bs.recs;
@@ -1013,7 +1013,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     if (big_bins) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_join, 0));
 #undef LAUNCH_VJOIN
     hipLaunchKernelGGL(gpc::k_gp_gather, dim3((maxparts + GPG_PARTS - 1) / GPG_PARTS, npairs), dim3(RM_THREADS), 0, c->stream,
-                       (const uint32_t*)c->staged.p, (const int32_t*)part, L, (const uint32_t*)vals, g.bs.recs, make_divw(W),
+                       (const uint32_t*)c->staged.p, (const int32_t*)part, L, g.bs.recs, make_divw(W),
                        mode, d_out, g.bs.out, cap, d_counts, (const int32_t*)c->stats.p, d_ncand);
     HIPCHK(c, hipGetLastError());
   }
@@ -1094,8 +1094,8 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   if (!c->h_flag) HIPCHK(c, hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocDefault));
   const uint32_t* codes = (const uint32_t*)c->codes.p;
   const uint8_t* wcand = wide_codes(c) ? d_cand : nullptr;
-  uint32_t* keys = (uint32_t*)c->gkeys[0].p;
-  uint32_t* vals = (uint32_t*)c->gvals[0].p;
+  CHK(ensure(c, c->gkv, sizeof(uint2) * (size_t)g.bs.recs * npairs));
+  uint2* kv = (uint2*)c->gkv.p;
   dim3 cgrid(L.nchunk, 2, npairs);
   int32_t *tabs = nullptr, *bincnt = nullptr;
   for (int attempt = 0;; ++attempt) {
@@ -1151,20 +1151,19 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     Timed t(c, KID_GLOBAL_SORT);
     if (L.nbins > 1024)
       hipLaunchKernelGGL((gpc::k_gp_scatter<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     else if (L.nbins > 256)
       hipLaunchKernelGGL((gpc::k_gp_scatter<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     else
       hipLaunchKernelGGL((gpc::k_gp_scatter<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), keys, vals, g.bs.recs);
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
     gpc::HtjArgs a;
-    a.keys = keys;
-    a.vals = vals;
+    a.kv = kv;
     a.tabs = tabs;
     a.stats = (const int32_t*)c->stats.p;
     a.staged = (uint2*)c->staged.p;
@@ -1378,7 +1377,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
-                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed, &c->gpart, &c->jstate};
+                    &c->hvals[0], &c->hvals[1], &c->hrec, &c->forest_dev, &c->packed, &c->gpart, &c->jstate, &c->gkv};
   while (!c->train_sets.empty()) (void)gpc_hip_train_set_destroy(c, c->train_sets.back());
   for (DevBuf* b : bufs) release(*b);
   for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

@@ -34,8 +34,7 @@ template <int RPT>
 struct HtjOcc { static constexpr int kWaves = RPT <= 4 ? 8 : 4; };
 
 struct HtjArgs {
-  const uint32_t* keys;    // [npairs][recs]: codes, left image's records then (at recs / 2) the right image's, by bin
-  const uint32_t* vals;    //                 pixel indices
+  const uint2* kv;         // [npairs][recs]: records (code, pixel index), left image's then (at recs / 2) the right image's, by bin
   const int32_t* tabs;     // scanned (bin, chunk) tables of k_gp_hist: entry (b, 0) = start of bin b
   const int32_t* stats;
   uint2* staged;           // [npairs][recs / 2]: (y << 14 | x left, right) of a bin's pairs from the bin's left start on
@@ -163,8 +162,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   HJ_STAMP(0);  // bin bounds (scalar loads)
   // one base per array and a 32-bit index (left records at ol + i, right ones at recs / 2 + orr + i - nl): per-lane
   // 64-bit pointers would cost two registers per record and array
-  const uint32_t* kb = a.keys + pair * a.recs;
-  const uint32_t* vb = a.vals + pair * a.recs;
+  const uint2* rb_ = a.kv + pair * a.recs;
   const uint32_t roff = (uint32_t)(a.recs / 2) + (uint32_t)orr - (uint32_t)nl;
 
   // ---- the bin's records -> registers (loads first, the counters are cleared under them).
@@ -179,8 +177,9 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
     if (i < n) {
       const bool right = i >= nl;
       const uint32_t idx = (uint32_t)i + (right ? roff : (uint32_t)ol);
-      code[j] = kb[idx];
-      const uint32_t pix = vb[idx];
+      const uint2 rec = rb_[idx];
+      code[j] = rec.x;
+      const uint32_t pix = rec.y;
       const uint32_t y = (uint32_t)divw(pix, a.dw);
       kv[j] = (right ? HTJ_SIDE : 0u) | (y << HTJ_XBITS) | (pix - y * (uint32_t)a.dw.W);
     }

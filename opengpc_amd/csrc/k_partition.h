@@ -235,7 +235,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gp_plan(const int32_t* __restric
   }
 }
 
-// grid: (nchunk, 2, npairs); records of side s of a pair live at keys / vals + pair * recs + s * (recs / 2).
+// grid: (nchunk, 2, npairs); records (code, pixel index) of side s of a pair live at kv + pair * recs + s * (recs / 2).
 // The chunk's pixels go through in tiles of GP_TILE: the tile's records are first put in bin order in LDS, then
 // written out by consecutive threads, so that every bin's run of a tile leaves as one contiguous piece.
 #ifndef GP_GROUPS
@@ -246,7 +246,7 @@ template <bool HT, int MB>
 __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __restrict__ codes,
                                                            const uint8_t* __restrict__ cand, int W, int H, long codes_stride,
                                                            const int32_t* __restrict__ tabs, GpLayout g, GpcDivW wd,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long recs) {
+                                                           uint2* __restrict__ kv, long recs) {
   typedef typename std::conditional<(MB > 256), uint16_t, uint8_t>::type bin_t;
   __shared__ int s_cur[MB];      // where the chunk's next record of a bin goes (global position)
   __shared__ __attribute__((aligned(16))) int s_tcnt[MB];  // records of the tile per bin, then their first place in the tile
@@ -258,8 +258,7 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
   const int tid = threadIdx.x;
   const int32_t* tab = tabs + (long)(pair * 2 + side) * g.nbins * g.nchunk;
   for (int i = tid; i < g.nbins; i += GPS_THREADS) s_cur[i] = tab[i * g.nchunk + chunk];
-  uint32_t* k = keys + pair * recs + side * (recs / 2);
-  uint32_t* v = vals + pair * recs + side * (recs / 2);
+  uint2* k = kv + pair * recs + side * (recs / 2);
   const int y0 = GPC_R + chunk * g.rows_per_chunk, y1 = min(y0 + g.rows_per_chunk, H - GPC_R);
   const long img = pair * codes_stride + (long)side * H * W;
   const uint32_t* im = codes + img;
@@ -347,8 +346,7 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
       if (j < ntile) {
         const uint32_t kk = s_key[j];
         const int pos = s_gofs[HT ? (uint32_t)s_bin[j] : kk >> g.bshift] + j;
-        k[pos] = kk;
-        v[pos] = s_val[j];
+        k[pos] = make_uint2(kk, s_val[j]);  // (one 8-byte store: half as many partial cache lines as two 4-byte arrays)
       }
     }
     __syncthreads();
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_scatter(const uint32_t* __re
 // array in partition order.  grid: (ceil(pmax / GPG_PARTS), npairs)
 #define GPG_PARTS 2
 __global__ __launch_bounds__(RM_THREADS) void k_gp_gather(const uint32_t* __restrict__ staged, const int32_t* __restrict__ part,
-                                                          GpLayout g, const uint32_t* __restrict__ vals, long recs, GpcDivW wd,
+                                                          GpLayout g, long recs, GpcDivW wd,
                                                           int mode, void* __restrict__ out, long out_stride_bytes, int cap,
                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ stats,
                                                           int32_t* __restrict__ ncand) {

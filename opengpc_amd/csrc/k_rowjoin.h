@@ -154,8 +154,9 @@ struct RjOcc {
 // index) of a contiguous code range per side instead of two image rows; a record's "x" is its position in the
 // partition, the disparity filter looks the pixel indices up, and results go to the partition's stretch of v.staged.
 struct RjVirt {
-  const uint32_t* keys;   // [npairs][recs]: side s of a pair at + s * (recs / 2)
-  const uint32_t* vals;   // pixel index y * W + x of the record
+  const uint2* kv;        // [npairs][recs]: records (code, pixel index y * W + x), side s of a pair at + s * (recs / 2).  One
+                          // 8-byte element per record: the scatter that writes them leaves runs of ~5 records per bin and
+                          // tile, and two 4-byte arrays made that twice as many partial cache lines (k_partition.h)
   int32_t* part;          // per pair (stride ps ints): cursors, partition offsets, match counts, misc (GpLayout)
   uint32_t* staged;       // [npairs][recs / 2] uint2: (left, right) pixel index of a partition's matches at its left offset
   long recs, ps;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   const uint32_t smask = (uint32_t)S - 1u;
   // VIRT: this workgroup's partition
   int32_t* vblk = nullptr;
-  const uint32_t *vkl = nullptr, *vkr = nullptr, *vvl = nullptr, *vvr = nullptr;
+  const uint2 *vrl = nullptr, *vrr = nullptr;  // the partition's records per side
   int v_nl = 0, v_nr = 0, v_offl = 0, v_p = 0;
   if (VIRT) {
     vblk = v.part + pair * v.ps;
@@ -405,10 +406,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     v_nr = vblk[v.o_off + v.pmax + 1 + p + 1] - offr;
     if (v_nl > NB || v_nr > NB) return;  // another launch's partition (or k_gp_plan has raised the overflow flag: the host takes the radix path)
     if (max(v_nl, v_nr) <= v.min_recs) return;
-    vkl = v.keys + pair * v.recs + v_offl;
-    vkr = v.keys + pair * v.recs + v.recs / 2 + offr;
-    vvl = v.vals + pair * v.recs + v_offl;
-    vvr = v.vals + pair * v.recs + v.recs / 2 + offr;
+    vrl = v.kv + pair * v.recs + v_offl;
+    vrr = v.kv + pair * v.recs + v.recs / 2 + offr;
   }
   int last_r = 0;
   if (!FUSE) last_r = VIRT ? vblk[v.o_misc + 2] /* GP_LASTR */ : img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
@@ -450,8 +449,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
         const int x = j * NT + tid;
-        ncl[j] = (x < v_nl) ? vkl[x] : RJ_EMPTY;
-        ncr[j] = (x < v_nr) ? vkr[x] : RJ_EMPTY;
+        ncl[j] = (x < v_nl) ? vrl[x].x : RJ_EMPTY;
+        ncr[j] = (x < v_nr) ? vrr[x].x : RJ_EMPTY;
         if (WIDE) {  // every record is a candidate: 0xFFFFFFFF is the key-less code
           if (x < v_nl && ncl[j] == RJ_EMPTY) nspl |= 1u << j;
           if (x < v_nr && ncr[j] == RJ_EMPTY) nspr |= 1u << j;
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
         if (VIRT) {  // positions carry no order here: the smallest PIXEL INDEX is the first in mask order
 #pragma unroll
           for (int j = 0; j < SPT; ++j)
-            if ((spr >> j) & 1u) atomicMin(&s_sp_minx, vvr[j * NT + tid]);
+            if ((spr >> j) & 1u) atomicMin(&s_sp_minx, vrr[j * NT + tid].y);
         } else {
           atomicMin(&s_sp_minx, (unsigned)((__ffs((int)spr) - 1) * NT + tid));
         }
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   if (WIDE && VIRT && spr) {  // which position holds the key-less right record with the smallest pixel index (read after the next barrier)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
-      if (((spr >> j) & 1u) && vvr[j * NT + tid] == s_sp_minx) s_sp_xv = (unsigned)(j * NT + tid);
+      if (((spr >> j) & 1u) && vrr[j * NT + tid].y == s_sp_minx) s_sp_xv = (unsigned)(j * NT + tid);
   }
 
   // ---- 2. every record finds its code's slot (read-only) and marks it.  The marks of a side go out
@@ -679,13 +678,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     for (int j = 0; j < SPT; ++j)
       if (kr[j] && kr[j] == tail_key) {
         atomicAdd(&s_tail_cnt, 1);
-        atomicMin(&s_tail_minx, VIRT ? vvr[j * NT + tid] : (unsigned)(j * NT + tid));
+        atomicMin(&s_tail_minx, VIRT ? vrr[j * NT + tid].y : (unsigned)(j * NT + tid));
       }
     if (VIRT) {  // positions carry no order: find where the tail record with the smallest pixel index sits
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < SPT; ++j)
-        if (kr[j] && kr[j] == tail_key && vvr[j * NT + tid] == s_tail_minx) s_tail_xv = (unsigned)(j * NT + tid);
+        if (kr[j] && kr[j] == tail_key && vrr[j * NT + tid].y == s_tail_minx) s_tail_xv = (unsigned)(j * NT + tid);
     }
   }
   __syncthreads();
@@ -731,7 +730,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     }
     if (good && apply_filter) {
       if (VIRT) {  // rectifiedMatch's filter on the two pixels (inference.hpp:384-391)
-        const uint32_t pl = vvl[j * NT + tid], pr = vvr[xr[j]];
+        const uint32_t pl = vrl[j * NT + tid].y, pr = vrr[xr[j]].y;
         const int yl = divw(pl, v.dw), yr = divw(pr, v.dw);
         good = abs(yl - yr) <= v.vtol && abs(((int)pl - yl * v.dw.W) - ((int)pr - yr * v.dw.W)) <= disp_high;
       } else {
@@ -856,7 +855,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
         // workgroup a moment ago (L2), where k_gp_gather fetched the same two words per match at random from memory
         // (83 -> 4x us per 8 pairs of 1920x1080 for that kernel)
         uint2* d2 = reinterpret_cast<uint2*>(v.staged) + pair * (v.recs / 2) + v_offl;
-        d2[rank] = make_uint2(vvl[j * NT + tid], vvr[xr[j]]);
+        d2[rank] = make_uint2(vrl[j * NT + tid].y, vrr[xr[j]].y);
       } else {
         dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
       }
