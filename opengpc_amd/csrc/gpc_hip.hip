@@ -185,6 +185,7 @@ struct gpc_hip_ctx {
   int rows_per_chunk = 16;    // GPC_HIP_ROWS_PER_CHUNK: rows one partition workgroup scatters (A/B checks)
   int gp_log2bins = 0;        // GPC_HIP_GP_LOG2BINS = 8 .. 11: force the number of code-range bins (A/B checks)
   int ht_hint_w = 0, ht_hint_h = 0, ht_hint_lbits = 0;  // what the hash-table planner ended on for the last image size: where it starts next time
+  bool ht_no_half = false;    // GPC_HIP_HT_NO_HALF: never the 512-thread k_ht_join (A/B checks)
   int ht_mid = 0;             // GPC_HIP_HT_MID = 10 .. 64: force HtjArgs::mid (A/B checks; 10 = one wave per bucket beyond ten records)
   int ht_lbits = 0;           // GPC_HIP_HT_LBITS = 7 .. 10: force the buckets per bin of the hash-table matcher (A/B checks)
   int gp_target = 2000;       // GPC_HIP_GP_TARGET: records per side a partition of the non-epipolar matcher aims at. Per 32 pairs of
@@ -666,6 +667,15 @@ int ensure_join_state(gpc_hip_ctx* c, size_t granules) {
   return GPC_OK;
 }
 
+// The second stream of the device-wide matchers: a launch for the few over-large partitions / bins runs beside the main one.
+int ensure_aux_stream(gpc_hip_ctx* c) {
+  if (c->s_aux) return GPC_OK;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
+  return GPC_OK;
+}
+
 // code images of npairs pairs -> supports / correspondences in d_out.
 // d_cand: the candidate bytes the hash kernel used ([2*npairs][H][W]: grad, or the scattered mask list)
 // mode 0: gpc_support, 1: gpc_correspondence, 2: packed supports (epipolar sort-match only; `po` says where)
@@ -987,11 +997,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     if (big_bins) {
       // The few over-large partitions first, on a stream of their own: their 8192-record workgroups (one per CU, 44-48 us
       // per 8 pairs of 1920x1080 as a launch by itself) run beside the 4096-record launch instead of after it.
-      if (!c->s_aux) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
-      }
+      CHK(ensure_aux_stream(c));
       HIPCHK(c, hipEventRecord(c->e_fork, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->s_aux, c->e_fork, 0));
       gpc::RjVirt v4 = v;
@@ -1181,13 +1187,39 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
     a.vtol = s->vertical_tolerance;
     a.apply_filter = (mode == 0);
     a.dw = make_divw(W);
-    const size_t lds = (size_t)8 * HTJ_THREADS * rpt;
-#define LAUNCH_HTJ(RPT)                                                                                                  \
+    // 512 threads where the bins are small (k_htjoin.h): at most 512 buckets, and bins of at most 2048 records; the few
+    // larger ones (a bucket of repeated states can double a bin) go to a 1024-thread launch on a stream of its own beside it
+    const bool half = rpt == 4 && lbits <= 9 && !c->ht_no_half &&
+                      (double)c->h_flag[2] / (double)L.nbins <= 0.9 * 512 * 4;  // the average bin fits comfortably
+    const bool split = half && c->h_flag[1] > 512 * 4;
+    a.min_recs = -1;
+    if (getenv("GPC_HIP_DEBUG_PLAN"))
+      fprintf(stderr, "[ht plan] lbits %d bins %d largest bin %d largest pair %d rpt %d half %d mid %d\n", lbits, L.nbins, c->h_flag[1],
+              c->h_flag[2], rpt, (int)half, a.mid);
+#define LAUNCH_HTJ(RPT, NT, STREAM)                                                                                      \
   do {                                                                                                                   \
-    CHK(allow_dyn_lds(c, reinterpret_cast<const void*>(gpc::k_ht_join<RPT>), lds));                                      \
-    hipLaunchKernelGGL(gpc::k_ht_join<RPT>, dim3(L.nbins, npairs), dim3(HTJ_THREADS), lds, c->stream, a);                \
+    const size_t lds_ = (size_t)8 * NT * RPT;                                                                            \
+    CHK(allow_dyn_lds(c, reinterpret_cast<const void*>(gpc::k_ht_join<RPT, NT>), lds_));                                 \
+    hipLaunchKernelGGL((gpc::k_ht_join<RPT, NT>), dim3(L.nbins, npairs), dim3(NT), lds_, STREAM, a);                     \
   } while (0)
-    if (rpt == 8) LAUNCH_HTJ(8); else LAUNCH_HTJ(4);
+    // (every bin is taken by exactly one launch: k_ht_check has seen that none exceeds the largest kernel's capacity)
+    if (rpt == 8) {
+      LAUNCH_HTJ(8, HTJ_THREADS, c->stream);
+    } else if (half) {
+      if (split) {
+        CHK(ensure_aux_stream(c));
+        HIPCHK(c, hipEventRecord(c->e_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->s_aux, c->e_fork, 0));
+        a.min_recs = 512 * 4;
+        LAUNCH_HTJ(4, HTJ_THREADS, c->s_aux);
+        HIPCHK(c, hipEventRecord(c->e_join, c->s_aux));
+        a.min_recs = -1;
+      }
+      LAUNCH_HTJ(4, 512, c->stream);
+      if (split) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_join, 0));
+    } else {
+      LAUNCH_HTJ(4, HTJ_THREADS, c->stream);
+    }
 #undef LAUNCH_HTJ
     hipLaunchKernelGGL(gpc::k_ht_gather, dim3((L.nbins + HTG_BINS - 1) / HTG_BINS, npairs), dim3(RM_THREADS), 0, c->stream, a,
                        mode, d_out, g.bs.out, cap, d_counts, d_ncand);
@@ -1327,6 +1359,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
     const int v = atoi(e);
     if (v >= 8 && v <= 11) c->gp_log2bins = v;
   }
+  c->ht_no_half = getenv("GPC_HIP_HT_NO_HALF") != nullptr;
   if (const char* e = getenv("GPC_HIP_HT_MID")) {
     const int v = atoi(e);
     if (v >= HM_CAP && v <= 64) c->ht_mid = v;

@@ -32,6 +32,9 @@ namespace gpc {
 // whose 839 bins of 256 buckets would still overflow 4096 records (1920x1080).
 template <int RPT>
 struct HtjOcc { static constexpr int kWaves = RPT <= 4 ? 8 : 4; };
+// k_ht_join<RPT, NT>: NT = 1024 threads is the rule; NT = 512 takes bins of at most 512 buckets and 2048 records -- 1920x1080:
+// 128 buckets of 13 records, 1664 per bin -- where 1024 threads left 60 % of their record slots empty and every wave issued the
+// whole instruction stream for them (four workgroups per CU instead of two).
 
 struct HtjArgs {
   const uint2* kv;         // [npairs][recs]: records (code, pixel index), left image's then (at recs / 2) the right image's, by bin
@@ -42,6 +45,8 @@ struct HtjArgs {
   long recs;
   int nbins, nchunk, epi, disp_high, vtol, apply_filter;
   int lbits;               // log2(buckets per bin): HTJ_LBITS, or less for large images (then only the first threads own a bucket)
+  int min_recs;            // this launch takes the bins with more than min_recs (and at most NT * RPT) records: the 512-thread
+                           // instantiation takes the bins up to 2048, a 1024-thread launch beside it the few larger ones
   int mid;                 // buckets with 11 .. mid records keep one thread per record, fuller ones are taken by a wave each
                            // (HM_CAP: every bucket with more than ten records goes to a wave -- the host's choice, see there)
   GpcDivW dw;
@@ -135,12 +140,12 @@ __device__ __forceinline__ int htj_rank_add(int rank, uint32_t oy, uint32_t oc, 
 // The kernel is bound by the number of LDS operations (random addresses, 32 waves per CU): a record is one 8-byte
 // LDS element, a bucket's start and count one word.
 // grid: (nbins, npairs); dynamic LDS: 8 * HTJ_THREADS * RPT bytes
-template <int RPT>
-__global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(HtjOcc<RPT>::kWaves, 8))) void k_ht_join(HtjArgs a) {
-  constexpr int HTJ_RPT = RPT, HTJ_CAP = HTJ_THREADS * RPT;
+template <int RPT, int NT = HTJ_THREADS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HtjOcc<RPT>::kWaves, 8))) void k_ht_join(HtjArgs a) {
+  constexpr int HTJ_RPT = RPT, HTJ_CAP = NT * RPT;
   extern __shared__ __attribute__((aligned(16))) uint2 htj_rec[];  // (code, side << 31 | y << 14 | x), by bucket
-  __shared__ uint32_t s_cs[HTJ_BUCKETS];    // records per bucket, then start | count << 16
-  __shared__ uint32_t s_bits[HTJ_BUCKETS];  // link bits, then emitted links | first output place << 10
+  __shared__ uint32_t s_cs[NT];    // records per bucket (thread b owns bucket b: 1 << a.lbits <= NT), then start | count << 16
+  __shared__ uint32_t s_bits[NT];  // link bits, then emitted links | first output place << 10
   __shared__ uint32_t s_list[HTJ_CAP / (HM_CAP + 1) + 1];  // the buckets with more than 10 records
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_nbig, s_nmid;
@@ -155,10 +160,8 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   const int nr = (bin + 1 < a.nbins ? tr[(long)(bin + 1) * a.nchunk] : NR) - orr;
   const int n = nl + nr;
   int32_t* bincnt = a.bincnt + (long)pair * a.nbins;
-  if (n > HTJ_CAP) {  // block-uniform; k_ht_check has sent such a batch to the radix path already
-    if (tid == 0) bincnt[bin] = 0;
-    return;
-  }
+  if (n > HTJ_CAP || n <= a.min_recs) return;  // block-uniform: another launch's bin (a bin beyond every launch: k_ht_check has
+                                                // sent the batch to the radix path already)
   HJ_STAMP(0);  // bin bounds (scalar loads)
   // one base per array and a 32-bit index (left records at ol + i, right ones at recs / 2 + orr + i - nl): per-lane
   // 64-bit pointers would cost two registers per record and array
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   uint32_t code[HTJ_RPT], kv[HTJ_RPT];
 #pragma unroll
   for (int j = 0; j < HTJ_RPT; ++j) {
-    const int i = j * HTJ_THREADS + tid;
+    const int i = j * NT + tid;
     code[j] = 0u;
     kv[j] = 0xFFFFFFFFu;  // no record
     if (i < n) {
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   uint32_t own_s;
   {
     uint32_t total;
-    own_s = gp_block_exscan(own_cnt, s_w, &total);
+    own_s = gp_block_exscan<NT / 64>(own_cnt, s_w, &total);
     s_cs[tid] = own_s | (own_cnt << 16);
     if (own_cnt > (uint32_t)a.mid) s_list[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
     else if (own_cnt > HM_CAP) s_nmid = 1u;  // (whoever writes, writes 1)
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
   {
     const int lane = tid & 63, wave = tid >> 6;
     const int nbig = (int)s_nbig;  // block-uniform
-    for (int k = wave; k < nbig; k += HTJ_THREADS / 64) {
+    for (int k = wave; k < nbig; k += NT / 64) {
       const int b = (int)s_list[k];
       const uint32_t w = s_cs[b];
       const int s0 = (int)(w & 0xFFFFu), nb = (int)(w >> 16);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(HTJ_THREADS) __attribute__((amdgpu_waves_per_eu(Htj
       emit = ht_walk_bits(w & 0x3FFu, (w >> 10) & 0x3FFu, m) & (w >> 20);
   }
   uint32_t total;
-  const uint32_t base = gp_block_exscan((uint32_t)__popc(emit), s_w, &total);
+  const uint32_t base = gp_block_exscan<NT / 64>((uint32_t)__popc(emit), s_w, &total);
   s_bits[tid] = emit | (base << 10);
   if (tid == 0) bincnt[bin] = (int32_t)total;
   uint2* st = a.staged + pair * (a.recs / 2) + ol;  // every pair has its own left record: at most nl of them

@@ -101,14 +101,15 @@ __global__ __launch_bounds__(GPS_THREADS) void k_gp_hist(const uint32_t* __restr
   for (int i = threadIdx.x; i < g.nbins; i += GPS_THREADS) tab[i * g.nchunk + chunk] = s_cnt[i];
 }
 
-// exclusive block scan of one value per thread (1024 threads); returns the exclusive prefix, *total gets the sum
+// exclusive block scan of one value per thread (NW waves); returns the exclusive prefix, *total gets the sum
+template <int NW = 16>  // waves of the workgroup
 __device__ __forceinline__ uint32_t gp_block_exscan(uint32_t v, uint32_t* s_w, uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan(v);
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
   uint32_t base = incl - v, tot = 0;
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < NW; ++w) {
     if (w < wave) base += s_w[w];
     tot += s_w[w];
   }
