@@ -149,6 +149,7 @@ struct gpc_hip_ctx {
   hipStream_t s_in = nullptr, s_out = nullptr, s_cnt = nullptr;
   hipStream_t s_aux = nullptr;            // the non-epipolar matcher's launch for over-large partitions runs beside the main one
   hipEvent_t e_fork = nullptr, e_join = nullptr;
+  hipEvent_t e_flag = nullptr;            // the device-wide matchers' plan words have arrived on the host
   hipEvent_t e_in[4] = {}, e_comp[4] = {}, e_cnt[4] = {}, e_out[4] = {};
   DevBuf packed;                  // packed results of the chunks in flight (3 slots)
   void* h_stage = nullptr;        // page-locked landing area of packed results (4 slots)
@@ -667,6 +668,11 @@ int ensure_join_state(gpc_hip_ctx* c, size_t granules) {
   return GPC_OK;
 }
 
+int ensure_flag_event(gpc_hip_ctx* c) {
+  if (!c->e_flag) HIPCHK(c, hipEventCreateWithFlags(&c->e_flag, hipEventDisableTiming));
+  return GPC_OK;
+}
+
 // The second stream of the device-wide matchers: a launch for the few over-large partitions / bins runs beside the main one.
 int ensure_aux_stream(gpc_hip_ctx* c) {
   if (c->s_aux) return GPC_OK;
@@ -943,10 +949,10 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->h_flag[0]) return GPC_OK;  // a single bin beyond 8192 records: the caller sorts instead
-  const bool big_bins = c->h_flag[2] > GP_NB;  // some partitions (single bins) need the 8192-record join
-  const int maxparts = c->h_flag[1] > 0 ? c->h_flag[1] : 1;
+  // (the scatter goes out before the host looks at the plan's words, as in the hash-table matcher below: the device works
+  // through the host's round trip; a batch that is sorted instead has scattered once for nothing)
+  CHK(ensure_flag_event(c));
+  HIPCHK(c, hipEventRecord(c->e_flag, c->stream));
   {
     Timed t(c, KID_GLOBAL_SORT);
     if (L.nbins > 1024)
@@ -960,6 +966,10 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
                          g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
     HIPCHK(c, hipGetLastError());
   }
+  HIPCHK(c, hipEventSynchronize(c->e_flag));
+  if (c->h_flag[0]) return GPC_OK;  // a single bin beyond 8192 records: the caller sorts instead
+  const bool big_bins = c->h_flag[2] > GP_NB;  // some partitions (single bins) need the 8192-record join
+  const int maxparts = c->h_flag[1] > 0 ? c->h_flag[1] : 1;
   {
     Timed t(c, KID_GLOBAL_MATCH);
     gpc::RjVirt v;
@@ -1103,19 +1113,21 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
   CHK(ensure(c, c->gkv, sizeof(uint2) * (size_t)g.bs.recs * npairs));
   uint2* kv = (uint2*)c->gkv.p;
   dim3 cgrid(L.nchunk, 2, npairs);
-  int32_t *tabs = nullptr, *bincnt = nullptr;
+  int32_t *tabs = nullptr, *bincnt = nullptr, *biglist = nullptr;
   for (int attempt = 0;; ++attempt) {
     L.bshift = lbits;
     L.nbins = (int)((HM_BUCKETS + (1u << lbits) - 1) >> lbits);  // 210 / 420 / 839 / 1678
     const size_t tab_ints = (size_t)2 * npairs * L.nbins * L.nchunk;
     const size_t cnt_ints = (size_t)npairs * L.nbins;
-    CHK(ensure(c, c->gpart, sizeof(int32_t) * (tab_ints + cnt_ints + 4)));
+    const size_t big_ints = (size_t)npairs * (HTJ_BIGCAP + 1);
+    CHK(ensure(c, c->gpart, sizeof(int32_t) * (tab_ints + cnt_ints + 4 + big_ints)));
     tabs = (int32_t*)c->gpart.p;
     bincnt = tabs + tab_ints;
     int32_t* d_flag = bincnt + cnt_ints;
+    biglist = d_flag + 4;
     {
       Timed t(c, KID_GLOBAL_KEYS);
-      HIPCHK(c, hipMemsetAsync(d_flag, 0, 3 * sizeof(int32_t), c->stream));
+      HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(int32_t) * (4 + big_ints), c->stream));
       if (L.nbins > 1024)
         hipLaunchKernelGGL((gpc::k_gp_hist<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H, g.bs.codes,
                            tabs, L, make_divw(W));
@@ -1128,11 +1140,29 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
       hipLaunchKernelGGL(gpc::k_g_scan, dim3(1, 2 * npairs), dim3(1024), 0, c->stream, tabs, L.nbins * L.nchunk,
                          (long)L.nbins * L.nchunk);
       hipLaunchKernelGGL(gpc::k_ht_check, dim3(npairs), dim3(256), 0, c->stream, (const int32_t*)tabs,
-                         (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * 4, d_flag);
+                         (const int32_t*)c->stats.p, L.nbins, L.nchunk, HTJ_THREADS * 4, d_flag, 512 * 4, biglist);
       HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_flag, d_flag, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    // The scatter goes out BEFORE the host looks at the plan's words (an event marks them): it does not depend on them --
+    // only whether its result is used does -- and the device then works through the host's round trip instead of idling
+    // (~15 us per call; a batch that has to be planned again, or sorted instead, has scattered once for nothing).
+    CHK(ensure_flag_event(c));
+    HIPCHK(c, hipEventRecord(c->e_flag, c->stream));
+  {
+    Timed t(c, KID_GLOBAL_SORT);
+    if (L.nbins > 1024)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
+    else if (L.nbins > 256)
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
+    else
+      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
+                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
+    HIPCHK(c, hipGetLastError());
+  }
+    HIPCHK(c, hipEventSynchronize(c->e_flag));
     if (!c->h_flag[0]) {  // every bin fits the 4096-record kernel
       c->ht_hint_w = W;
       c->ht_hint_h = H;
@@ -1152,19 +1182,6 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
       break;
     }
     return GPC_OK;  // the caller sorts instead
-  }
-  {
-    Timed t(c, KID_GLOBAL_SORT);
-    if (L.nbins > 1024)
-      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 2048>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
-    else if (L.nbins > 256)
-      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 1024>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
-    else
-      hipLaunchKernelGGL((gpc::k_gp_scatter<true, 256>), cgrid, dim3(GPS_THREADS), 0, c->stream, codes, wcand, W, H,
-                         g.bs.codes, (const int32_t*)tabs, L, make_divw(W), kv, g.bs.recs);
-    HIPCHK(c, hipGetLastError());
   }
   {
     Timed t(c, KID_GLOBAL_MATCH);
@@ -1193,14 +1210,17 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
                       (double)c->h_flag[2] / (double)L.nbins <= 0.9 * 512 * 4;  // the average bin fits comfortably
     const bool split = half && c->h_flag[1] > 512 * 4;
     a.min_recs = -1;
+    a.use_list = 0;
+    a.biglist = biglist;
     if (getenv("GPC_HIP_DEBUG_PLAN"))
       fprintf(stderr, "[ht plan] lbits %d bins %d largest bin %d largest pair %d rpt %d half %d mid %d\n", lbits, L.nbins, c->h_flag[1],
               c->h_flag[2], rpt, (int)half, a.mid);
+    dim3 hgrid(L.nbins, npairs);
 #define LAUNCH_HTJ(RPT, NT, STREAM)                                                                                      \
   do {                                                                                                                   \
     const size_t lds_ = (size_t)8 * NT * RPT;                                                                            \
     CHK(allow_dyn_lds(c, reinterpret_cast<const void*>(gpc::k_ht_join<RPT, NT>), lds_));                                 \
-    hipLaunchKernelGGL((gpc::k_ht_join<RPT, NT>), dim3(L.nbins, npairs), dim3(NT), lds_, STREAM, a);                     \
+    hipLaunchKernelGGL((gpc::k_ht_join<RPT, NT>), hgrid, dim3(NT), lds_, STREAM, a);                                     \
   } while (0)
     // (every bin is taken by exactly one launch: k_ht_check has seen that none exceeds the largest kernel's capacity)
     if (rpt == 8) {
@@ -1211,9 +1231,15 @@ int run_hashtable_partition(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, i
         HIPCHK(c, hipEventRecord(c->e_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->s_aux, c->e_fork, 0));
         a.min_recs = 512 * 4;
+        if (c->h_flag[3] <= HTJ_BIGCAP) {  // the larger bins' list is the grid (else: every bin, nearly all returning at once)
+          a.use_list = 1;
+          hgrid = dim3(c->h_flag[3] > 0 ? c->h_flag[3] : 1, npairs);
+        }
         LAUNCH_HTJ(4, HTJ_THREADS, c->s_aux);
         HIPCHK(c, hipEventRecord(c->e_join, c->s_aux));
         a.min_recs = -1;
+        a.use_list = 0;
+        hgrid = dim3(L.nbins, npairs);
       }
       LAUNCH_HTJ(4, 512, c->stream);
       if (split) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_join, 0));
@@ -1426,6 +1452,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
       (void)hipEventDestroy(c->e_out[i]);
     }
   }
+  if (c->e_flag) (void)hipEventDestroy(c->e_flag);
   if (c->s_aux) {
     (void)hipStreamDestroy(c->s_aux);
     (void)hipEventDestroy(c->e_fork);

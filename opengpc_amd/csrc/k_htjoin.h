@@ -45,6 +45,8 @@ struct HtjArgs {
   long recs;
   int nbins, nchunk, epi, disp_high, vtol, apply_filter;
   int lbits;               // log2(buckets per bin): HTJ_LBITS, or less for large images (then only the first threads own a bucket)
+  const int32_t* biglist;  // [npairs][1 + HTJ_BIGCAP]: count, then the bins with more than 2048 records (k_ht_check)
+  int use_list;            // 1: workgroup b takes bin biglist[pair][1 + b] (the launch's grid is the longest list of the batch)
   int min_recs;            // this launch takes the bins with more than min_recs (and at most NT * RPT) records: the 512-thread
                            // instantiation takes the bins up to 2048, a 1024-thread launch beside it the few larger ones
   int mid;                 // buckets with 11 .. mid records keep one thread per record, fuller ones are taken by a wave each
@@ -88,8 +90,9 @@ __device__ __forceinline__ uint32_t htj_row(uint32_t kv) { return (kv >> HTJ_XBI
 
 // Raises the overflow word if some bin holds more records than one workgroup takes (known once the chunk tables are
 // scanned: before anything is scattered).  grid: (npairs); 256 threads
+#define HTJ_BIGCAP 1024  // entries of a pair's list of bins beyond the 512-thread join (more: that launch covers the whole grid)
 __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __restrict__ stats, int nbins, int nchunk,
-                           int cap, int32_t* __restrict__ overflow) {
+                           int cap, int32_t* __restrict__ overflow, int split_at, int32_t* __restrict__ biglist) {
   const int pair = blockIdx.x;
   const int32_t* tl = tabs + (long)(pair * 2) * nbins * nchunk;
   const int32_t* tr = tl + (long)nbins * nchunk;
@@ -99,6 +102,10 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
     const int nl = (bin + 1 < nbins ? tl[(long)(bin + 1) * nchunk] : NL) - tl[(long)bin * nchunk];
     const int nr = (bin + 1 < nbins ? tr[(long)(bin + 1) * nchunk] : NR) - tr[(long)bin * nchunk];
     mx = max(mx, nl + nr);
+    if (nl + nr > split_at) {  // the work list of the 1024-thread launch beside the 512-thread one: [count | bins] per pair
+      const int at = atomicAdd(&biglist[(long)pair * (HTJ_BIGCAP + 1)], 1);
+      if (at < HTJ_BIGCAP) biglist[(long)pair * (HTJ_BIGCAP + 1) + 1 + at] = bin;
+    }
   }
   // (one atomic per wave: one per bin on a single word took 19 us per batch of 8 at 1678 bins)
   mx = (int)wave_max_u32((uint32_t)mx);
@@ -107,6 +114,8 @@ __global__ void k_ht_check(const int32_t* __restrict__ tabs, const int32_t* __re
     atomicMax(overflow + 1, mx);  // the batch's largest bin: the host sizes its next attempt by it
   }
   if (threadIdx.x == 0) atomicMax(overflow + 2, NL + NR);  // the batch's largest pair: records per bucket (HtjArgs::mid)
+  __syncthreads();  // the list's length is final
+  if (threadIdx.x == 0) atomicMax(overflow + 3, biglist[(long)pair * (HTJ_BIGCAP + 1)]);
 }
 
 // rank += (oy : oc : okv) < (y : c : kv) as 96-bit numbers, i.e. "state, then insertion order": a borrow chain.
@@ -149,7 +158,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HtjOcc<RPT>:
   __shared__ uint32_t s_list[HTJ_CAP / (HM_CAP + 1) + 1];  // the buckets with more than 10 records
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_nbig, s_nmid;
-  const int bin = blockIdx.x, pair = blockIdx.y;
+  const int pair = blockIdx.y;
+  int bin = blockIdx.x;
+  if (a.use_list) {  // block-uniform
+    const int32_t* bl = a.biglist + (long)pair * (HTJ_BIGCAP + 1);
+    if (bin >= bl[0]) return;
+    bin = bl[1 + bin];
+  }
   const int tid = threadIdx.x;
   HJ_STAMP_INIT();
   const int32_t* tl = a.tabs + (long)(pair * 2) * a.nbins * a.nchunk;
