@@ -138,9 +138,11 @@ def compulsory_bytes(W, H, B, M_step, fused=True):
     what the roofline of that kernel is priced on.  M = supports of the step.  `fused`: the join writes the 12-byte
     supports itself (one launch); otherwise it stages 4-byte words and k_gather_rows expands them."""
     rows = H - 26
+    # the gradient image between the two is one BIT per pixel in the batched pipelines (GPC_HIP_NO_GRAD_BITS keeps the bytes)
+    g = 1.0 if os.environ.get("GPC_HIP_NO_GRAD_BITS") else 0.125
     d = {
-        "k_preprocess": 6.0 * W * H * B,                          # raw read (1 B/px), smooth + grad written, both images
-        "k_hash": 12.0 * W * H * B,                               # smooth + grad read, dense 4-byte code image written, both images
+        "k_preprocess": 2.0 * (2.0 + g) * W * H * B,              # raw read (1 B/px), smooth + grad written, both images
+        "k_hash": 2.0 * (5.0 + g) * W * H * B,                    # smooth + grad read, dense 4-byte code image written, both images
     }
     if fused:
         d["k_row_join"] = 8.0 * W * rows * B + 12.0 * M_step      # both code rows read, 12-byte supports written
@@ -151,8 +153,11 @@ def compulsory_bytes(W, H, B, M_step, fused=True):
 
 
 def bytes_text(fused):
-    return {"k_row_join": "8 B per pixel of the joined rows + %d B per support" % (12 if fused else 4), "k_hash": "12 B per pixel",
-            "k_preprocess": "6 B per pixel", "k_gather_rows": "16 B per support"}
+    g = 1.0 if os.environ.get("GPC_HIP_NO_GRAD_BITS") else 0.125
+    return {"k_row_join": "8 B per pixel of the joined rows + %d B per support" % (12 if fused else 4),
+            "k_hash": "%.2f B per pixel of a pair (smooth 1 + gradient %.3f read, code 4 written, two images)" % (2 * (5 + g), g),
+            "k_preprocess": "%.2f B per pixel of a pair (raw 1 read, smooth 1 + gradient %.3f written, two images)" % (2 * (2 + g), g),
+            "k_gather_rows": "16 B per support"}
 
 
 def main():

@@ -159,6 +159,8 @@ struct gpc_hip_ctx {
   int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
   size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
+  bool grad_is_bits = false;      // c->grad holds k_preprocess's bit image (set by run_preprocess, read by run_hash)
+  bool no_grad_bits = false;      // GPC_HIP_NO_GRAD_BITS: the batched pipelines keep the byte image (A/B checks)
   int upload_mode = 1;            // GPC_HIP_UPLOAD: single-pair host path -- 0: hipMemcpyAsync per side, 1: one k_upload2 launch, 2: k_preprocess reads the host's pages
   int direct_max = 2;             // GPC_HIP_DIRECT_MAX: batches up to this size with a page-locked `out` are written by the
                                   // kernels straight into the caller's array (no packed records, no host expansion); 0 = never
@@ -513,8 +515,9 @@ int run_hashtable_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_sett
                         void* d_out, int cap, int32_t* d_counts, int32_t* d_ncand);
 
 // raw0/raw1 device pointers; fills smooth, grad for npairs*sides images
+// gradbits: the caller's only reader of the gradient image is run_hash (a batched pipeline): it may leave as one bit per pixel
 int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1, int W, int H,
-                   int npairs, int sides, int thr) {
+                   int npairs, int sides, int thr, bool gradbits = false) {
   const int nimg = npairs * sides;
   const size_t n = (size_t)W * H;
   CHK(ensure(c, c->smooth, n * nimg));
@@ -529,14 +532,19 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   const int rows = small ? PP_ROWS_SMALL : PP_ROWS;
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
-  snprintf(c->launch_name[KID_PREPROCESS], sizeof c->launch_name[0], "gpc::k_preprocess<%s, %d>", c->naive ? "true" : "false", rows);
-#define LAUNCH_PRE(NAIVE, ROWS)                                                                              \
-  hipLaunchKernelGGL((gpc::k_preprocess<NAIVE, ROWS>), grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1, \
+  // (the SSE=OFF arithmetic keeps the byte image: its 32-test codes need the candidate BYTES in the matchers, wide_codes())
+  c->grad_is_bits = gradbits && !c->naive && !c->no_grad_bits;
+  snprintf(c->launch_name[KID_PREPROCESS], sizeof c->launch_name[0], "gpc::k_preprocess<%s, %d%s>", c->naive ? "true" : "false", rows,
+           c->grad_is_bits ? ", true" : "");
+#define LAUNCH_PRE(NAIVE, ROWS, BITS)                                                                        \
+  hipLaunchKernelGGL((gpc::k_preprocess<NAIVE, ROWS, BITS>), grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1, \
                      (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p)
   if (c->naive) {
-    if (small) LAUNCH_PRE(true, PP_ROWS_SMALL); else LAUNCH_PRE(true, PP_ROWS);
+    if (small) LAUNCH_PRE(true, PP_ROWS_SMALL, false); else LAUNCH_PRE(true, PP_ROWS, false);
+  } else if (c->grad_is_bits) {
+    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL, true); else LAUNCH_PRE(false, PP_ROWS, true);
   } else {
-    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL); else LAUNCH_PRE(false, PP_ROWS);
+    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL, false); else LAUNCH_PRE(false, PP_ROWS, false);
   }
 #undef LAUNCH_PRE
   HIPCHK(c, hipGetLastError());
@@ -571,12 +579,21 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
-  snprintf(c->launch_name[KID_HASH], sizeof c->launch_name[0], "gpc::k_hash<%s, %s, %s>", tau ? "true" : "false",
-           dense ? "true" : "false", c->naive ? "true" : "false");
+  snprintf(c->launch_name[KID_HASH], sizeof c->launch_name[0], "gpc::k_hash<%s, %s, %s%s>", tau ? "true" : "false",
+           dense ? "true" : "false", c->naive ? "true" : "false",
+           (c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive) ? ", true" : "");
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
                      d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + (NAIVE ? 1 : 0), st, tpw)
-  if (c->naive) {
+  // the gradient image is k_preprocess's bit image: the batched SSE pipelines (run_preprocess(..., gradbits))
+  const bool gbits = c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive;
+  if (gbits) {
+#define LAUNCH_HASH_BITS(TAU)                                                                                  \
+  hipLaunchKernelGGL((gpc::k_hash<TAU, false, false, true>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
+                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p, st, tpw)
+    if (tau) LAUNCH_HASH_BITS(true); else LAUNCH_HASH_BITS(false);
+#undef LAUNCH_HASH_BITS
+  } else if (c->naive) {
     if (tau && dense) LAUNCH_HASH(true, true, true);
     else if (tau) LAUNCH_HASH(true, false, true);
     else if (dense) LAUNCH_HASH(false, true, true);
@@ -1407,6 +1424,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   const char* et = getenv("GPC_HIP_EXPAND_THREADS");
   if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
   if (const char* e = getenv("GPC_HIP_UPLOAD")) c->upload_mode = atoi(e);
+  c->no_grad_bits = getenv("GPC_HIP_NO_GRAD_BITS") != nullptr;
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
   c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
@@ -1683,6 +1701,7 @@ int gpc_hip_hash_codes(gpc_hip_ctx* c, const uint8_t* smooth, const uint8_t* gra
   CHK(ensure(c, c->codes, sizeof(uint32_t) * n));
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE));
   HIPCHK(c, hipMemcpyAsync(c->smooth.p, smooth, n, hipMemcpyHostToDevice, c->stream));
+  c->grad_is_bits = false;  // the caller's byte image
   HIPCHK(c, hipMemcpyAsync(c->grad.p, grad, n, hipMemcpyHostToDevice, c->stream));
   // the reference's zero-filled gpcstates buffer (inference.hpp:274): the kernel writes the candidate rows only
   HIPCHK(c, hipMemsetAsync(c->codes.p, 0, sizeof(uint32_t) * n, c->stream));
@@ -1718,6 +1737,7 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
   uint8_t* d_cm = (uint8_t*)c->candmap.p;
   HIPCHK(c, hipMemcpyAsync(d_sm, smoothL, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_sm + n, smoothR, n, hipMemcpyHostToDevice, c->stream));
+  c->grad_is_bits = false;  // the caller's byte images
   HIPCHK(c, hipMemcpyAsync(d_gr, gradL, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_gr + n, gradR, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(d_cm, 0, 2 * n, c->stream));
@@ -1773,7 +1793,7 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)W * H;
   CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
-  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold, true));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
                (uint32_t*)c->codes.p));
   CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out, cap_per_pair, d_counts, d_ncand));
@@ -1881,7 +1901,7 @@ int gpc_hip_match_batch_device_packed(gpc_hip_ctx* c, const uint8_t* d_rawL, con
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)W * H;
   CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
-  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold, true));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
                (uint32_t*)c->codes.p));
   const PackedOut po = {d_rows, (long)cap_per_pair, (long)H};
@@ -1948,7 +1968,7 @@ static int match_batch_direct(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     HIPCHK(c, hipMemcpyAsync(d_l, rawL, n * npairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_r, rawR, n * npairs, hipMemcpyHostToDevice, c->stream));
   }
-  CHK(run_preprocess(c, d_l, d_r, W, H, npairs, 2, s->gradient_threshold));
+  CHK(run_preprocess(c, d_l, d_r, W, H, npairs, 2, s->gradient_threshold, true));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false, (uint32_t*)c->codes.p));
   CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out_host, cap, d_cnt, d_cnt + npairs));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2151,7 +2171,7 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     if (k >= 3) HIPCHK(c, hipStreamWaitEvent(c->stream, c->e_out[(k - 3) & 3], 0));  // chunk k-3 has left this result slot
     uint8_t* slot = d_pk + (size_t)(k % 3) * cb;
     CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * pc));
-    CHK(run_preprocess(c, d_l, d_r, W, H, pc, 2, s->gradient_threshold));
+    CHK(run_preprocess(c, d_l, d_r, W, H, pc, 2, s->gradient_threshold, true));
     CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * pc, false, (uint32_t*)c->codes.p));
     const PackedOut po = {reinterpret_cast<int32_t*>(slot), 0l, (long)hpad, d_tot + (size_t)(k % 3) * chunk};
     CHK(run_match(c, W, H, pc, s, 2, (const uint8_t*)c->grad.p, slot + 4 * hpad * chunk, cap, (int32_t*)c->counts.p + p0,

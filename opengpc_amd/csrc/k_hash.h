@@ -232,7 +232,9 @@ __device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & SW_
 #else
 #define HT_OCC
 #endif
-template <bool TAU, bool DENSE, bool NAIVE>
+// GBITS: `grad` is k_preprocess<..., BITS>'s bit image (one bit per pixel); a lane fetches the 16 bits of its 16-pixel group:
+// "any gradient in the group" is that word != 0 (where the byte image needs two DPP permutes), its own nibble the candidates.
+template <bool TAU, bool DENSE, bool NAIVE, bool GBITS = false>
 __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   const int img = bz;
   const long n = (long)W * H;
   const uint8_t* sm = smooth + (long)img * n;
-  const uint8_t* gr = grad + (long)img * n;
+  static_assert(!GBITS || (!DENSE && !NAIVE), "the bit image exists in the batched SSE pipelines only");
+  const uint8_t* gr = grad + (long)img * (GBITS ? n / 8 : n);
   const uint8_t* cm = candmap ? candmap + (long)img * n : nullptr;
   uint32_t* out = codes + (long)img * n;
   const int tx0 = bx * HT_X;
@@ -305,7 +308,10 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int y = ty0 + wave * RPW + r;
-      pg[r] = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (uint32_t)(y * W + x0)) : 0u;
+      if (GBITS)  // the group's 16 bits (2-byte aligned: W is a multiple of 16)
+        pg[r] = (x0 < W && y < H) ? (uint32_t)*reinterpret_cast<const uint16_t*>(gr + ((uint32_t)(y * W + (x0 & ~15)) >> 3)) : 0u;
+      else
+        pg[r] = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (uint32_t)(y * W + x0)) : 0u;
     }
     const int base = (ty0 - GPC_R) * W;  // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
 #pragma unroll
@@ -381,11 +387,17 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
     const uint32_t g4 = gq[r];  // 0 outside the image
     uint32_t c4 = g4;
     if (cm) c4 = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(cm + (uint32_t)(y * W + x0)) : 0u;
-    const uint32_t cb = (y < H - GPC_R) ? (swar_nonzero(c4) & xmask) : 0u;
+    uint32_t cb;
+    if (GBITS && !cm) {  // own nibble -> bit 7 of byte j (n * 0x10204080: bit j lands on 7, 15, 23, 31; the other products fall elsewhere)
+      const uint32_t nib = (g4 >> (x0 & 15)) & 0xFu;
+      cb = (y < H - GPC_R) ? ((nib * 0x10204080u) & SW_H & xmask) : 0u;
+    } else {
+      cb = (y < H - GPC_R) ? (swar_nonzero(c4) & xmask) : 0u;
+    }
     // the reference skips 16-pixel groups (4 lanes here) without any gradient byte (filter.hpp:566):
-    // OR over the quad of lanes with two DPP quad permutes
+    // OR over the quad of lanes with two DPP quad permutes (GBITS: the fetched word is the group's)
     uint32_t gany = g4;
-    if (!NAIVE) {
+    if (!NAIVE && !GBITS) {
       gany |= (uint32_t)__builtin_amdgcn_mov_dpp((int)gany, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
       gany |= (uint32_t)__builtin_amdgcn_mov_dpp((int)gany, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
     }

@@ -81,7 +81,11 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
 // smooth/grad: [npairs*sides][H][W]
 // NAIVE = the reference built with SSE=OFF: boxNaive (sum/9) and sobelNaive (C integer division,
 // no lane duplication), both over output positions W+1 .. (H-1)*W (filter.hpp:157-223).
-template <bool NAIVE, int ROWS>
+// BITS (SSE arithmetic only): the gradient image is binary (0 / 255), and inside the batched pipelines its only reader is the
+// hash kernel's candidate test -- so it leaves as ONE BIT per pixel (grad[img][(y * W + x) / 8], bit x % 8; W % 16 == 0):
+// 2.125 instead of 3 bytes of traffic per pixel in a kernel that runs at the device's copy rate.  The entry points that hand
+// the gradient image to the host (gpc_hip_preprocess) keep the byte image.
+template <bool NAIVE, int ROWS, bool BITS = false>
 __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
     const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
     uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   const long n = (long)W * H;
   const uint8_t* raw = (side ? raw1 : raw0) + (long)pair * n;
   uint8_t* sm = smooth + (long)img * n;
-  uint8_t* gr = grad + (long)img * n;
+  uint8_t* gr = grad + (long)img * (BITS ? n / 8 : n);
 
   if (bx == 0 && by == 0 && threadIdx.x == 0) {
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_NCAND] = 0;
@@ -189,7 +193,12 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
         }
       }
     }
-    if (PP_PX == 16)
+    if (BITS) {  // (PP_PX == 8: one byte of the bit image per thread and row; bit i = byte i of the strip is non-zero)
+      static_assert(!BITS || (PP_PX == 8 && !NAIVE), "the bit image is written by 8-pixel strips of the SSE arithmetic");
+      const uint32_t lo = gw[0] & 0x01010101u, hi = gw[1] & 0x01010101u;  // bytes are 0x00 / 0xFF
+      const uint32_t m = (((lo * 0x01020408u) >> 24) & 0xFu) | ((((hi * 0x01020408u) >> 24) & 0xFu) << 4);  // bit 0 of byte i -> bit i
+      gr[((long)y * W + x0) >> 3] = (uint8_t)m;
+    } else if (PP_PX == 16)
       *reinterpret_cast<uint4*>(gr + (long)y * W + x0) = make_uint4(gw[0], gw[1], gw[PP_PX / 4 - 2], gw[PP_PX / 4 - 1]);
     else
       *reinterpret_cast<uint2*>(gr + (long)y * W + x0) = make_uint2(gw[0], gw[1]);
