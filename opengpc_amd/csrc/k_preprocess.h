@@ -42,10 +42,10 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
     // last byte (the naive filters' window at position (H-1)*W reaches it)
     if (r == H && x0 == 0) p[0] = raw[n - 1];
   } else {
-    long k = (long)r * W + x0;
+    const int k = r * W + x0;  // (an image has at most 2^30 pixels, check_dims: 32-bit offsets inside it)
     uint32_t w[PP_PX / 4];
 #if !defined(PP_NARROW_LOADS) && PP_PX == 8
-    if (k >= 4 && k + 12 <= n) {
+    if (k >= 4 && k + 12 <= (int)n) {
       // ONE 16-byte load (4-byte aligned) brings the strip and both neighbours, bytes k-4 .. k+11, where the
       // 8-byte load + two byte loads below issue three instructions (measured on one box: 172 -> 148 us per
       // 256 pairs; only the image's first and last strip take the other path)
@@ -64,7 +64,7 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
       w[0] = v.x; w[1] = v.y;
     }
     p[0] = (k - 1 >= 0) ? raw[k - 1] : 0;
-    p[PP_PX + 1] = (k + PP_PX < n) ? raw[k + PP_PX] : 0;
+    p[PP_PX + 1] = (k + PP_PX < (int)n) ? raw[k + PP_PX] : 0;
     }
     // (taking these two neighbour bytes from the adjacent lanes with wave_shr / wave_shl DPP moves instead, memory
     // only at the wave's ends, measured SLOWER on the same box: 230 vs 191 us per 256 pairs)
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
       }
     }
     if (PP_PX == 16)
-      *reinterpret_cast<uint4*>(sm + (long)y * W + x0) = make_uint4(sw[0], sw[1], sw[PP_PX / 4 - 2], sw[PP_PX / 4 - 1]);
+      *reinterpret_cast<uint4*>(sm + (uint32_t)(y * W + x0)) = make_uint4(sw[0], sw[1], sw[PP_PX / 4 - 2], sw[PP_PX / 4 - 1]);
     else
-      *reinterpret_cast<uint2*>(sm + (long)y * W + x0) = make_uint2(sw[0], sw[1]);
+      *reinterpret_cast<uint2*>(sm + (uint32_t)(y * W + x0)) = make_uint2(sw[0], sw[1]);
 
     // ---- sobel
     uint32_t gw[PP_PX / 4];
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
       static_assert(!BITS || (PP_PX == 8 && !NAIVE), "the bit image is written by 8-pixel strips of the SSE arithmetic");
       const uint32_t lo = gw[0] & 0x01010101u, hi = gw[1] & 0x01010101u;  // bytes are 0x00 / 0xFF
       const uint32_t m = (((lo * 0x01020408u) >> 24) & 0xFu) | ((((hi * 0x01020408u) >> 24) & 0xFu) << 4);  // bit 0 of byte i -> bit i
-      gr[((long)y * W + x0) >> 3] = (uint8_t)m;
+      gr[(uint32_t)(y * W + x0) >> 3] = (uint8_t)m;
     } else if (PP_PX == 16)
-      *reinterpret_cast<uint4*>(gr + (long)y * W + x0) = make_uint4(gw[0], gw[1], gw[PP_PX / 4 - 2], gw[PP_PX / 4 - 1]);
+      *reinterpret_cast<uint4*>(gr + (uint32_t)(y * W + x0)) = make_uint4(gw[0], gw[1], gw[PP_PX / 4 - 2], gw[PP_PX / 4 - 1]);
     else
-      *reinterpret_cast<uint2*>(gr + (long)y * W + x0) = make_uint2(gw[0], gw[1]);
+      *reinterpret_cast<uint2*>(gr + (uint32_t)(y * W + x0)) = make_uint2(gw[0], gw[1]);
   }
 }
 
