@@ -308,8 +308,12 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int y = ty0 + wave * RPW + r;
+#ifdef HT_EXP_NOGRAD
+      if (GBITS) pg[r] = 0xFFFFu + (uint32_t)(y & 0);
+#else
       if (GBITS)  // the group's 16 bits (2-byte aligned: W is a multiple of 16)
         pg[r] = (x0 < W && y < H) ? (uint32_t)*reinterpret_cast<const uint16_t*>(gr + ((uint32_t)(y * W + (x0 & ~15)) >> 3)) : 0u;
+#endif
       else
         pg[r] = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (uint32_t)(y * W + x0)) : 0u;
     }
@@ -320,8 +324,16 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
       pv[i] = make_uint4(0, 0, 0, 0);
       pn[i] = 0;
       if (cflag[i] & 1u) {  // one unsigned compare per range check (k wraps above the buffer when it is negative)
+#if defined(HT_EXP_NOWINDOW)
+        pv[i] = make_uint4(k, k * 3u, k * 5u, k * 7u);
+        pn[i] = k * 11u;
+#elif defined(HT_EXP_NOPN)
+        if (k <= nbytes - 16u) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
+        pn[i] = k * 11u;
+#else
         if (k <= nbytes - 16u) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
         if ((cflag[i] & 2u) && k + 16u <= nbytes - 4u) pn[i] = *reinterpret_cast<const uint32_t*>(sm + (k + 16u));
+#endif
       }
     }
   };
@@ -473,7 +485,13 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
         const bool is_cand = (cand8[r] >> (8 * j + 7)) & 1u;
         op[j] = DENSE ? ((NAIVE && !is_cand) ? 0u : c) : (is_cand ? c : GPC_NOCAND);
       }
+#if defined(HT_EXP_NOSTORE)   // experiment: how much of the kernel is the code image's write stream?
+      if (o.x == 0x12345678u && W < 0) *reinterpret_cast<uint4*>(out + (uint32_t)(y * W + x0)) = o;
+#elif defined(HT_EXP_HALFSTORE)
+      if ((lane & 1) == 0) *reinterpret_cast<uint4*>(out + (uint32_t)(y * W + x0)) = o;
+#else
       *reinterpret_cast<uint4*>(out + (uint32_t)(y * W + x0)) = o;
+#endif
     }
     if (cand8[r]) { cnt += __popc(cand8[r]); last = y; }
   }
