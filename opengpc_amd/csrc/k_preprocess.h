@@ -77,6 +77,40 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
   for (int i = 0; i < PP_PX + 2; ++i) o.a[i] = p[i];
 }
 
+// The same in two steps (PP_PX == 8): the row's 16 bytes k-4 .. k+11 as they lie in memory -- left neighbour in the top byte
+// of .x, the strip in .y / .z, the right neighbour in the low byte of .w; zeros where the reference reads nothing -- and their
+// unpacking.  EXPERIMENT (-DPP_PREFETCH, -DPP_DEPTH=n): a thread requests rows ahead of the one it unpacks instead of one load
+// per loop iteration, used at once.  Slower at every depth (all rows: 183 us, 88 VGPRs; 1 / 2 / 3 ahead: 150 / 152 / 162 us
+// against 140-147): eight waves per SIMD hide the round trips better than the registers of a deeper pipeline do.
+__device__ __forceinline__ uint4 pre_fetch_row(const uint8_t* __restrict__ raw, int n, int W, int H, int r, int x0) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (r < 0 || r >= H) {
+    if (r == H && x0 == 0) v.x = (uint32_t)raw[n - 1] << 24;
+    return v;
+  }
+  const int k = r * W + x0;
+  if (k >= 4 && k + 12 <= n) return *reinterpret_cast<const uint4*>(raw + k - 4);
+  const uint2 w = *reinterpret_cast<const uint2*>(raw + k);  // the image's first and last strip
+  v.y = w.x;
+  v.z = w.y;
+  v.x = (k - 1 >= 0) ? ((uint32_t)raw[k - 1] << 24) : 0u;
+  v.w = (k + 8 < n) ? (uint32_t)raw[k + 8] : 0u;
+  return v;
+}
+template <bool NAIVE>
+__device__ __forceinline__ void pre_unpack_row(const uint4 v, PreRow& o) {
+  static_assert(PP_PX == 8, "16 bytes hold an 8-pixel strip and its neighbours");
+  int p[PP_PX + 2];
+  p[0] = (int)(v.x >> 24);
+  p[PP_PX + 1] = (int)(v.w & 0xFFu);
+#pragma unroll
+  for (int i = 0; i < PP_PX; ++i) p[1 + i] = ((i < 4 ? v.y : v.z) >> (8 * (i % 4))) & 0xFF;
+#pragma unroll
+  for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
+#pragma unroll
+  for (int i = 0; i < PP_PX + 2; ++i) o.a[i] = p[i];
+}
+
 // raw0/raw1: [npairs][H][W] for side 0 / 1 (raw1 unused when sides == 1)
 // smooth/grad: [npairs*sides][H][W]
 // NAIVE = the reference built with SSE=OFF: boxNaive (sum/9) and sobelNaive (C integer division,
@@ -85,8 +119,13 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
 // hash kernel's candidate test -- so it leaves as ONE BIT per pixel (grad[img][(y * W + x) / 8], bit x % 8; W % 16 == 0):
 // 2.125 instead of 3 bytes of traffic per pixel in a kernel that runs at the device's copy rate.  The entry points that hand
 // the gradient image to the host (gpc_hip_preprocess) keep the byte image.
+#ifdef PP_WAVES_PER_EU
+#define PP_OCC __attribute__((amdgpu_waves_per_eu(PP_WAVES_PER_EU, PP_WAVES_PER_EU)))
+#else
+#define PP_OCC
+#endif
 template <bool NAIVE, int ROWS, bool BITS = false>
-__global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
+__global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
     const uint8_t* __restrict__ raw0, const uint8_t* __restrict__ raw1, uint8_t* __restrict__ smooth,
     uint8_t* __restrict__ grad, int W, int H, int sides, int thr_sq, int32_t* __restrict__ img_stats) {
   // XCD-aware block order (see k_hash.h): launch-order neighbours sit on different XCDs; remapped, each
@@ -128,16 +167,35 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
   const int box_last = NAIVE ? H - 3 : ((H & 1) ? H - 3 : H - 4);
 
   PreRow rows[3];
+#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
+#ifndef PP_DEPTH
+#define PP_DEPTH 2   // rows requested ahead of the one being unpacked
+#endif
+  constexpr int PD = PP_DEPTH < ROWS ? PP_DEPTH : ROWS;
+  uint4 rv[ROWS + 2];  // the rows of the strip this thread touches; row i + 2 + PD is requested while row i + 2 is unpacked
+#pragma unroll
+  for (int i = 0; i < 2 + PD; ++i) rv[i] = pre_fetch_row(raw, (int)n, W, H, ys - 1 + i, x0);
+  pre_unpack_row<NAIVE>(rv[0], rows[0]);
+  pre_unpack_row<NAIVE>(rv[1], rows[1]);
+#else
   pre_load_row<NAIVE>(raw, n, W, H, ys - 1, x0, rows[0]);
   pre_load_row<NAIVE>(raw, n, W, H, ys, x0, rows[1]);
+#endif
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
     const int y = ys + i;
     if (y >= H) break;
+    const bool row_in = true;
     PreRow& up = rows[i % 3];
     PreRow& mid = rows[(i + 1) % 3];
     PreRow& dn = rows[(i + 2) % 3];
+#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
+    if (i + 2 + PD < ROWS + 2) rv[i + 2 + PD] = pre_fetch_row(raw, (int)n, W, H, ys + 1 + i + PD, x0);
+    asm volatile("" ::: "memory");  // (keeps the requests where they are: hoisted to the top they cost the kernel its occupancy)
+    pre_unpack_row<NAIVE>(rv[i + 2], dn);
+#else
     pre_load_row<NAIVE>(raw, n, W, H, y + 1, x0, dn);
+#endif
 
     // ---- box + clearBoundary
     uint32_t sw[PP_PX / 4];
@@ -152,13 +210,15 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
         sw[j / 4] |= (uint32_t)v << (8 * (j % 4));
       }
     }
-    if (PP_PX == 16)
+    if (!row_in) {
+    } else if (PP_PX == 16)
       *reinterpret_cast<uint4*>(sm + (uint32_t)(y * W + x0)) = make_uint4(sw[0], sw[1], sw[PP_PX / 4 - 2], sw[PP_PX / 4 - 1]);
     else
       *reinterpret_cast<uint2*>(sm + (uint32_t)(y * W + x0)) = make_uint2(sw[0], sw[1]);
 
     // ---- sobel
     uint32_t gw[PP_PX / 4];
+    uint32_t gm = 0u;  // BITS: the strip's eight gradient bits
 #pragma unroll
     for (int q = 0; q < PP_PX / 4; ++q) gw[q] = 0;
     if (NAIVE) {
@@ -188,16 +248,17 @@ __global__ __launch_bounds__(PP_TX * PP_TY) void k_preprocess(
           const int l2 = dn.a[q], c2 = dn.a[q + 1], r2 = dn.a[q + 2];
           const int gx = ninth(l0 + l2 + 2 * l1) - ninth(r0 + r2 + 2 * r1);
           const int gy = ninth(l0 + r0 + 2 * c0) - ninth(l2 + r2 + 2 * c2);
-          const uint32_t e = (gx * gx + gy * gy > thr_sq) ? 0xFFFFu : 0u;
-          gw[g8 * 2 + j / 2] |= e << (16 * (j % 2));
+          const bool edge = gx * gx + gy * gy > thr_sq;
+          if (BITS) gm |= edge ? (3u << (2 * j)) : 0u;  // decision j shows on pixels 2j and 2j + 1
+          const uint32_t e = edge ? 0xFFFFu : 0u;
+          if (!BITS) gw[g8 * 2 + j / 2] |= e << (16 * (j % 2));
         }
       }
     }
-    if (BITS) {  // (PP_PX == 8: one byte of the bit image per thread and row; bit i = byte i of the strip is non-zero)
+    if (!row_in) {
+    } else if (BITS) {  // (PP_PX == 8: one byte of the bit image per thread and row; bit i = pixel x0 + i has gradient)
       static_assert(!BITS || (PP_PX == 8 && !NAIVE), "the bit image is written by 8-pixel strips of the SSE arithmetic");
-      const uint32_t lo = gw[0] & 0x01010101u, hi = gw[1] & 0x01010101u;  // bytes are 0x00 / 0xFF
-      const uint32_t m = (((lo * 0x01020408u) >> 24) & 0xFu) | ((((hi * 0x01020408u) >> 24) & 0xFu) << 4);  // bit 0 of byte i -> bit i
-      gr[(uint32_t)(y * W + x0) >> 3] = (uint8_t)m;
+      gr[(uint32_t)(y * W + x0) >> 3] = (uint8_t)gm;
     } else if (PP_PX == 16)
       *reinterpret_cast<uint4*>(gr + (uint32_t)(y * W + x0)) = make_uint4(gw[0], gw[1], gw[PP_PX / 4 - 2], gw[PP_PX / 4 - 1]);
     else
