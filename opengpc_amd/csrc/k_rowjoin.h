@@ -536,6 +536,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     for (int j = 0; j < SPT; ++j) {  // stored key = code + 1 (0 = no record in this pixel slot)
       kl[j] = ncl[j] + 1u;
       kr[j] = ncr[j] + 1u;
+#ifdef RJ_DBG_EMPTY   // experiment: every pixel slot without a record -- what a row costs before it holds anything
+      kl[j] = kr[j] = 0u * (ncl[j] + ncr[j]);
+#endif
+#ifdef RJ_DBG_LEFTONLY  // experiment: no right records (inserts and left lookups only)
+      kr[j] = 0u * ncr[j];
+#endif
     }
     if (WIDE) {
       spl = nspl;
