@@ -1997,6 +1997,7 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
       (void)hipStreamSynchronize(c->s_out);
       (void)hipStreamSynchronize(c->s_cnt);
     }
+    if (c->s_aux) (void)hipStreamSynchronize(c->s_aux);
     (void)hipStreamSynchronize(c->stream);
   }
   return st;
