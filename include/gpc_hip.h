@@ -156,11 +156,13 @@ int gpc_hip_match_pair(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* raw
  * d_ncand[npairs][2] candidate counts.
  * With the reference's sparsematch settings (epipolar_mode = 1, use_hashtable = 0) the call is
  * ASYNCHRONOUS on the context's stream: three launches are queued and it returns.
- * With epipolar_mode = 0 or use_hashtable = 1 (the device-wide matchers) it SYNCHRONISES the stream
- * once or twice inside the call: those matchers partition the records by code / bucket range and read
- * one word back to learn whether every partition fits a workgroup (if not -- heavily repeated codes --
- * the whole batch takes the radix-sort path instead).  In either case the outputs may be read only
- * after gpc_hip_synchronize (or another wait on the stream).
+ * With epipolar_mode = 0 or use_hashtable = 1 (the device-wide matchers) the HOST WAITS once inside the
+ * call (the hash-table matcher once per planning attempt): those matchers partition the records by code /
+ * bucket range and read a few words back to learn whether every partition fits a workgroup (if not -- heavily
+ * repeated codes -- the whole batch takes the radix-sort path instead).  The wait is for an event in the middle
+ * of what the call queues, not for the stream; part of their work runs on a second stream of the context that
+ * is joined back into the context's stream before the call returns.  In either case the outputs may be read
+ * only after gpc_hip_synchronize (or another wait on the stream).
  * The join that writes the supports places a row behind the rows before it with a bounded wait on
  * other workgroups; a wait that ran out (not observed so far) is reported by the next
  * gpc_hip_synchronize as GPC_E_HIP and the outputs of that launch must not be used. */
