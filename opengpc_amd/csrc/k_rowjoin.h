@@ -469,8 +469,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       uint32_t tl[SPT], tr[SPT];
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
+#ifdef RJ_DBG_NOLOAD     // (experiment, with RJ_DBG_EMPTY only: what the rows' loads cost)
+        tl[j] = (uint32_t)(j * NT + tid) * 3u;
+        tr[j] = (uint32_t)(j * NT + tid) * 5u;
+#else
         tl[j] = rl[(uint32_t)(j * NT + tid)];
         tr[j] = rr_[(uint32_t)(j * NT + tid)];
+#endif
       }
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
@@ -556,7 +561,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
       const uint4 zero = make_uint4(z0, z0, z0, z0);
       const int nclear = FUSE ? (S + 4 + S / 2) / 4 : (8 * (S + 1) + 15) / 16;  // FUSE: keys + halfword flags; D is not cleared
+#ifndef RJ_DBG_NOCLEAR   // (experiment, with RJ_DBG_EMPTY only: what the table clear costs)
       for (int i = tid; i < nclear; i += NT) z[i] = zero;
+#endif
     }
     if (tid == 0) {
       // (constants made here for the same reason as the zeros above: hoisted out of the row loop they are spilled to
@@ -828,7 +835,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       }
     }
   }
+#ifndef RJ_DBG_NOSCAN    // (experiment, with RJ_DBG_EMPTY only)
   block_exscan<SPT, NT>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b, r_cnt[NB] = number of matches
+#endif
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) r_key[r_cnt[rb[j]] + rs[j]] = kl[j] - 1u;  // the code (WIDE: the key-less 0xFFFFFFFF ranks last)
