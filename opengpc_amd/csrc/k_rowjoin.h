@@ -300,8 +300,28 @@ __device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, in
 // Wide rows use more threads per row before more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
 // The cnt ranked words (xL | xR << 16) of row y of `pair` leave as records base .. base + cnt - 1 of the pair's array.
+// The kernel's own arguments as they lie in the kernel-argument segment (HIP lays the parameters out in order, each at its
+// natural alignment): rj_out_args() reads the OUTPUT parameters of RjFuse from there at their point of use.  As by-value
+// arguments they were loaded once, kept for the whole persistent kernel and -- at 80 SGPRs for eight waves per SIMD --
+// spilled to VGPR lanes: eight v_readlane per row and wave to get them back, where one s_load_dwordx8 does it now.
+struct RjKernargs {
+  const uint32_t* codes; const uint8_t* cand; int W, H, disp_high, apply_filter; const int32_t* img_stats; uint32_t* staged;
+  int32_t* rowcnt; int log2s, rpw; RjVirt v; RjFuse f;
+};
+struct RjOutArgs { int mode; void* out; int cap; int32_t* counts; int32_t* ncand; int32_t* rows_out; long packed_stride, rows_stride; };
+__device__ __forceinline__ RjOutArgs rj_out_args() {
+  typedef const char __attribute__((address_space(4))) kchar;
+  kchar* p = (kchar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RjKernargs, f);
+  asm volatile("" : "+s"(p));  // (opaque: a load through it is made where it is used, not hoisted to the kernel's top)
+  const RjFuse __attribute__((address_space(4)))* f = (const RjFuse __attribute__((address_space(4)))*)p;
+  RjOutArgs o;
+  o.mode = f->mode; o.out = f->out; o.cap = f->cap; o.counts = f->counts; o.ncand = f->ncand; o.rows_out = f->rows_out;
+  o.packed_stride = f->packed_stride; o.rows_stride = f->rows_stride;
+  return o;
+}
+
 template <int NT>
-__device__ __forceinline__ void rj_emit_row(const RjFuse& f, const uint32_t* __restrict__ words, uint32_t cnt, uint32_t base,
+__device__ __forceinline__ void rj_emit_row(const RjOutArgs& f, const uint32_t* __restrict__ words, uint32_t cnt, uint32_t base,
                                             int pair, int y, int tid) {
 #ifdef RJ_DBG_NOEMIT
   return;
@@ -826,12 +846,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   RJ_STAMP(4);
   if (FUSE && d_t >= 0) {  // the pending row's records leave (D is rewritten by this row's walk, two barriers on)
     const uint32_t base = s_base;
-    rj_emit_row<NT>(f, d_words, d_cnt, base, d_pair, d_y, tid);
+    const RjOutArgs fo = rj_out_args();
+    rj_emit_row<NT>(fo, d_words, d_cnt, base, d_pair, d_y, tid);
     if (d_t == nrows - 1 && tid == 0) {  // the pair's last row knows the total
-      f.counts[d_pair] = (int32_t)(base + d_cnt);
-      if (f.ncand) {
-        f.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-        f.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+      fo.counts[d_pair] = (int32_t)(base + d_cnt);
+      if (fo.ncand) {
+        fo.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+        fo.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
       }
     }
   }
@@ -908,12 +929,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       }
       __syncthreads();
       const uint32_t base = s_base;
-      rj_emit_row<NT>(f, d_words, d_cnt, base, d_pair, d_y, tid);
+      const RjOutArgs fo = rj_out_args();
+      rj_emit_row<NT>(fo, d_words, d_cnt, base, d_pair, d_y, tid);
       if (d_t == nrows - 1 && tid == 0) {
-        f.counts[d_pair] = (int32_t)(base + d_cnt);
-        if (f.ncand) {
-          f.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-          f.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+        fo.counts[d_pair] = (int32_t)(base + d_cnt);
+        if (fo.ncand) {
+          fo.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
+          fo.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
         }
       }
     }
