@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the openGPC hot path (preprocess + hash + match) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+is the ONE command at any N: with N > 1 and no WORLD_SIZE in the environment the script starts its own N rank processes
+(one per GPU, RCCL between them) before anything touches a GPU, relays rank 0's JSON line and exits with the ranks' status;
+it fails loudly when fewer than N devices are visible (GPC_DIST_BACKEND=gloo: rehearsal with the ranks sharing the devices
+there are).  Under a launcher that exports RANK / WORLD_SIZE itself --
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+-- every process is one rank, as before.
 
 One step = one pass of the whole timed region of the reference's sparsematch
 (samples/sparsematch.cpp:45-52: preprocessImage x2 + rectifiedMatch) over one batch of
@@ -53,6 +59,44 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (HIP streams + workspaces) the steps alternate over; 1 = strictly serial steps")
     return ap.parse_args()
+
+
+class HostChild:
+    """This rank's torch-free child for the host-to-host leg (tools/pcie_inclusive.py --serve): the child makes the
+    synchronous gpc_hip_match_batch calls on the library's own ROCm runtime, this process tells it when (after the
+    barrier between the ranks) and collects the child's own timing of each call."""
+
+    def __init__(self, B, W, H, forest, dev_index):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "pcie_inclusive.py"), "--serve", str(B), str(W),
+                                   str(H), forest, str(dev_index)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+    def _line(self):
+        line = self.p.stdout.readline()
+        if not line:
+            raise RuntimeError("host-to-host child ended early (status %r)" % (self.p.poll(),))
+        return line.strip()
+
+    def wait_ready(self):
+        while self._line() != "ready":
+            pass
+
+    def call(self):
+        self.p.stdin.write("go\n")
+        self.p.stdin.flush()
+        return float(self._line())
+
+    def finish(self):
+        self.p.stdin.write("done\n")
+        self.p.stdin.flush()
+        rec = json.loads(self._line())
+        self.p.stdin.close()
+        self.p.wait(timeout=120)
+        return rec
+
+    def kill(self):
+        if self.p.poll() is None:
+            self.p.kill()
 
 
 def host_cores():
@@ -162,14 +206,20 @@ def bytes_text(fused):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, BEFORE anything initialises a GPU here
+        from opengpc_amd.launch import launch_local_ranks
+        raise SystemExit(launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                            backend=os.environ.get("GPC_DIST_BACKEND", "nccl")))
     import numpy as np
     import torch
 
     from opengpc_amd import dist as gdist
 
     rank, world, local_rank = gdist.env_world()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d: the launcher's rank count and --gpus must agree "
+                         "(run `python bench.py --gpus N` plainly and it starts its own N ranks)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # GPC_DIST_BACKEND=gloo: rehearsal of the N > 1 line on a box with fewer GPUs than ranks (the ranks share the devices
@@ -290,25 +340,49 @@ def main():
     # ---- the reference's own timed region on EVERY rank at once: raw pairs in page-locked host memory -> gpc_support
     #      arrays in host memory, one synchronous gpc_hip_match_batch call per rank and repetition, barrier-bracketed
     #      (the ranks of a node share the host's memory bandwidth and CPUs, so they are timed together); the slowest
-    #      rank of a repetition counts.  At one rank this is `pcie_inclusive.in_this_process`.
-    host_reps, host_times, host_ok, host_threads = 9, [], True, 0
+    #      rank of a repetition counts.  The host API has no torch dependency, and a process that has imported torch runs
+    #      every HIP library on the ROCm runtime bundled with the torch wheel (an older one than the /opt/rocm this library
+    #      is built against; its copies are slower: 8.7 vs 5.6 ms per 256 pairs).  So every rank makes the calls in a
+    #      CHILD process without torch -- the C++ caller's situation -- and this process only carries the barriers and
+    #      tells the child when to go.  At one rank the same call is also timed inside this process, for the record.
+    host_reps, host_times, host_ok, host_threads, child_rec = 15, [], True, 0, None
+    inproc_times = []
     if not args.no_extras or args.host_path:
-        capi_cap = 300000
-        Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
-        Lp[:] = Lh
-        Rp[:] = Rh
-        outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
-        res = {}
+        child = HostChild(B, W, H, args.forest, dev_index)
+        try:
+            child.wait_ready()                    # 5 untimed calls: page-locked buffers touched, workers and clocks warm
 
-        def host_call():
-            res["r"] = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
-        for _ in range(3):
-            host_call()
-        host_times = gdist.timed_calls(host_call, host_reps)
-        o_, c_, n_, st_ = res["r"]
-        host_ok = bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts))
-        host_threads = int(ctx.L.gpc_hip_host_threads(ctx.h))
-        del Lp, Rp, outb
+            def child_call():
+                res_t.append(child.call())
+            res_t = []
+            gdist.timed_calls(child_call, host_reps)   # barrier before each repetition; the child times its own call
+            host_times = res_t
+            child_rec = child.finish()
+        finally:
+            child.kill()
+        ch_counts = np.asarray(child_rec.pop("counts"), np.int64)
+        crc = child_rec.pop("crc32")
+        import zlib
+        host_ok = bool(child_rec["status"] == 0 and np.array_equal(ch_counts, counts))
+        for j in sorted(set((0, B // 2, B - 1))):   # the device path's 12-byte records of three pairs, byte for byte
+            host_ok = host_ok and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
+        host_threads = int(child_rec.get("host", {}).get("expand_threads", 0))
+        if world == 1:
+            capi_cap = 300000
+            Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
+            Lp[:] = Lh
+            Rp[:] = Rh
+            outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
+            res = {}
+
+            def host_call():
+                res["r"] = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
+            for _ in range(3):
+                host_call()
+            inproc_times = sorted(gdist.timed_calls(host_call, 9))
+            o_, c_, n_, st_ = res["r"]
+            host_ok = host_ok and bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts))
+            del Lp, Rp, outb
 
     # O(100 B) per rank over xGMI: timing / counters only, never pixel data
     row = [float(B), float(ncand.sum()), float(counts.sum()), 1.0 if verified in (True, None) else 0.0,
@@ -328,9 +402,11 @@ def main():
                     "ms_per_call_min": round(float(hs[0]) * 1e3, 3), "ms_per_call_max": round(float(hs[-1]) * 1e3, 3),
                     "identical_to_device_path": bool(float(allr[:, 5].min()) >= 1.0),
                     "expand_threads_per_rank": int(allr[:, 6].min()),
+                    "measured_in": "one child process without torch per rank (the library's own ROCm runtime), told when to "
+                                   "go by its rank between the ranks' barriers; each call timed by the child itself",
                     "note": "every rank's synchronous gpc_hip_match_batch call at the same moment (barrier before each "
-                            "repetition), all pairs of all ranks / the slowest rank's time, median of %d repetitions after 3 "
-                            "untimed; from this process, whose HIP runtime is the one bundled with torch" % nh}
+                            "repetition), all pairs of all ranks / the slowest rank's time, median of %d repetitions after 5 "
+                            "untimed" % nh}
     t_med = float(win[len(win) // 2])
     pairs_per_step = float(allr[:, 0].sum())
 
@@ -378,15 +454,17 @@ def main():
             "avg_launch_us": round(dom_us, 2),
             "launches_timed": dom_n,
             "pipeline_alg_bytes_per_pair": a_pair,
-            "pipeline_frac": round(a_pair * pairs_per_step * args.steps / t_med / 1e9 / HBM_PEAK_GBS, 4),
+            "pipeline_alg_GBs_equivalent": round(a_pair * pairs_per_step * args.steps / t_med / 1e9, 1),
             "pipeline_compulsory_frac": round(sum(alg.values()) * world * args.steps / t_med / 1e9 / HBM_PEAK_GBS, 4),
             "note": "achieved = bytes the dominant kernel must read + write per launch given its formats (DESIGN.md 3: "
                     "%s) / mean HIP-event duration of its %d launches inside the timed windows, on the stream it runs on.  "
                     "The kernel keeps the reference's sort in LDS and is bound by LDS / issue, not by HBM: `frac` says how "
                     "far below the HBM roof that leaves it.  `traffic` is not measured by this script; "
                     "`traffic_from_profiles` = 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes.  "
-                    "pipeline_frac = SURVEY 8d's A*pairs/t/peak; pipeline_compulsory_frac = sum of the kernels' "
-                    "compulsory bytes / step time / peak." % (BYTES_TEXT.get(dom_slot, ""), dom_n),
+                    "pipeline_alg_GBs_equivalent = SURVEY 8d's A*pairs/t: the rate a matcher whose sort streams through HBM "
+                    "would need for this throughput -- NOT traffic and not a fraction of anything (this build's sort never "
+                    "leaves LDS, so it can exceed the peak); pipeline_compulsory_frac = sum of the kernels' compulsory bytes / "
+                    "step time / peak." % (BYTES_TEXT.get(dom_slot, ""), dom_n),
             "kernels": kinfo,
         }
 
@@ -407,43 +485,28 @@ def main():
             del a, b
             roofline["copy_measured_GBs"] = round(copy_gbs, 1)
 
-        # ---- the reference's own timed region: raw pairs in (pinned) host memory -> gpc_support arrays in host
-        #      memory, one synchronous gpc_hip_match_batch call per batch (H2D + kernels + packed D2H + expansion on
-        #      worker threads, overlapped in chunks).  The host API has no torch dependency, and a process that has
-        #      imported torch runs every HIP library on the ROCm runtime bundled with the torch wheel (an older one
-        #      than the /opt/rocm this library is built against; its copies are slower).  So the call is timed in a
-        #      child process without torch -- the C++ caller's situation -- and, for the record, in this process too.
+        # ---- `pcie_inclusive`: the reference's own timed region (host images -> host gpc_support arrays,
+        #      sparsematch.cpp:45-52) -- the all-ranks record measured above in torch-free children; at one rank with
+        #      the same call inside this (torch) process beside it
         pcie, single_h2h = None, None
-        if world == 1 and not args.no_extras:
-            import subprocess
-            import zlib
-            try:
-                outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pcie_inclusive.py"), "--one", str(B), str(W),
-                                       str(H), args.forest], check=True, capture_output=True, text=True, timeout=300).stdout
-                pcie = json.loads(outp.strip().splitlines()[-1])
-                ch_counts = np.asarray(pcie.pop("counts"), np.int64)
-                crc = pcie.pop("crc32")
-                same = bool(pcie["status"] == 0 and np.array_equal(ch_counts, counts))
-                for j in (0, B // 2, B - 1):   # the device path's 12-byte records of three pairs, byte for byte
-                    same = same and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
-                pcie["identical_to_device_path"] = same
-                single_h2h = pcie.pop("single_pair_host_to_host", None)
-                pcie["measured_in"] = "child process without torch (the library's own ROCm runtime)"
-                pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of 15 calls after 5 untimed"
-            except Exception as e:  # the headline does not depend on it
-                pcie = None
-                print("bench.py: pcie_inclusive child failed: %r" % (e,), file=sys.stderr)
-            # the same call inside this (torch) process: measured on every rank above
-            if pcie is None:
-                pcie = dict(host_all, measured_in="this process (torch's bundled ROCm runtime)") if host_all else None
-            elif host_all:
-                pcie["in_this_process"] = host_all
-        elif host_all:   # world > 1: all ranks at once (no torch-free child per rank)
-            pcie = dict(host_all, measured_in="the bench processes themselves, all ranks at once",
-                        timed_region="host images -> host gpc_support arrays (sparsematch.cpp:45-52)")
+        if host_all:
+            pcie = dict(host_all)
+            pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of %d calls after 5 untimed" % nh
+            if child_rec:
+                single_h2h = child_rec.pop("single_pair_host_to_host", None)
+                for k in ("host_buffers", "bytes_in", "bytes_over_the_link_out", "bytes_delivered", "host"):
+                    if k in child_rec:
+                        pcie[k + ("_rank0" if world > 1 and k != "host_buffers" else "")] = child_rec[k]
+            if inproc_times:
+                ti = inproc_times[len(inproc_times) // 2]
+                pcie["in_this_process"] = {"ms_per_call": round(ti * 1e3, 3), "value": round(2.0 * W * H * B / ti / 1e6, 1),
+                                           "unit": "Mpix/s", "ms_per_call_min": round(inproc_times[0] * 1e3, 3),
+                                           "ms_per_call_max": round(inproc_times[-1] * 1e3, 3),
+                                           "note": "the same call from this process, whose HIP runtime is the one bundled with torch"}
 
+        # the CPU leg: rank 0 only, at any N (after the last collective: the other ranks are done and idle)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, W, H)
 
         # the same steps alternating over TWO streams/workspaces (step k+1 overlaps step k); reported

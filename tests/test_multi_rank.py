@@ -90,6 +90,71 @@ def test_two_ranks_shard_pairs_without_overlap():
     assert job["mpix_per_s"] == pytest.approx(2 * W * H * world * PER_RANK * 2 / job["t_max"] / 1e6)
 
 
+RANK_PROG = """
+import json, os, sys
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["LOCAL_WORLD_SIZE"] == str(w)
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and r == 1:
+    sys.exit(7)
+if len(sys.argv) > 1 and sys.argv[1] == "fail":
+    import time
+    time.sleep(60)          # the launcher must stop this rank when rank 1 fails
+print(json.dumps({"rank": r, "world": w}))
+"""
+
+
+def run_launcher(tmp_path, n, ndev, backend, arg=None):
+    """launch_local_ranks in a process of its own (its rank 0 inherits that process's stdout)."""
+    prog = tmp_path / "rank_prog.py"
+    prog.write_text(RANK_PROG)
+    drv = ("import sys; sys.path.insert(0, %r)\n"
+           "from opengpc_amd.launch import launch_local_ranks\n"
+           "assert 'torch' not in sys.modules\n"
+           "rc = launch_local_ranks(%d, [sys.executable, %r] + %r, backend=%r, count_devices=lambda: %d)\n"
+           "assert 'torch' not in sys.modules      # the launching process stays torch- and GPU-free\n"
+           "sys.exit(rc)\n" % (ROOT, n, str(prog), [arg] if arg else [], backend, ndev))
+    return subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_n_ranks_and_relays_rank0(tmp_path):
+    import json
+    r = run_launcher(tmp_path, 3, 8, "nccl")
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip()) == {"rank": 0, "world": 3}          # rank 0's line alone on stdout
+    others = sorted(json.loads(l)["rank"] for l in r.stderr.strip().splitlines() if l.startswith("{"))
+    assert others == [1, 2]
+
+
+def test_launcher_refuses_fewer_devices_than_ranks(tmp_path):
+    r = run_launcher(tmp_path, 4, 1, "nccl")
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout == ""
+    r = run_launcher(tmp_path, 2, 0, "gloo")
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+    r = run_launcher(tmp_path, 2, 1, "gloo")        # rehearsal: the ranks share the one device
+    assert r.returncode == 0 and '"world": 2' in r.stdout
+
+
+def test_launcher_failing_rank_stops_the_job(tmp_path):
+    import time
+    t0 = time.time()
+    r = run_launcher(tmp_path, 3, 8, "nccl", "fail")
+    assert r.returncode == 7 and "rank 1 exited with status 7" in r.stderr
+    assert time.time() - t0 < 30     # ranks 0 and 2 were stopped, not waited for
+
+
+def test_bench_plainly_with_gpus_2_without_a_gpu_fails_loudly():
+    """`python bench.py --gpus 2` is the driver's command: without a device it must say so and return non-zero (here, in
+    the CPU container) -- never a line with fewer ranks than asked for."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.returncode == 2 and "no HIP device" in r.stderr and r.stdout == ""
+
+
 def test_single_process_helpers():
     assert gdist.shard_indices(3, 8, 4) == [3, 11, 19, 27]
     stats = gdist.gather_stats([0.5, 32, 10, 5])
@@ -123,3 +188,31 @@ def test_rccl_path_rehearsal_on_one_gpu(tmp_path):
     hh = line["host_to_host_all_ranks"]
     assert hh["ranks"] == 1 and hh["pairs_per_call_per_rank"] == 16 and hh["value"] > 100 and hh["identical_to_device_path"] is True
     assert 1 <= hh["expand_threads_per_rank"] <= 32
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_plainly_starts_two_ranks():
+    """The driver's command at N = 2, run plainly (no torchrun, no RANK / WORLD_SIZE): bench.py starts its own two ranks.
+    On a one-GPU box the ranks share the device (GPC_DIST_BACKEND=gloo carries the barriers; RCCL refuses two ranks on one
+    device); the line must be a complete two-rank line: n_gpus 2, the CPU leg, the host-to-host leg of BOTH ranks measured in
+    torch-free children."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env.update(GPC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GPC_BENCH_NO_SINGLE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--windows", "3", "--batch", "16", "--verify-pairs", "3", "--cpu-seconds", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line: rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "pairs-dp2" and line["scaling"] == "weak"
+    assert line["verified_vs_oracle"] is True and line["verified_pairs"] == 6          # 3 per rank
+    assert line["pairs_per_s"] > 0 and line["value"] > 1000
+    cb = line["cpu_baseline"]
+    assert cb and cb["cores"] == 1 and cb["value"] > 0 and cb["kind"] in ("port", "reference")
+    hh = line["host_to_host_all_ranks"]
+    assert hh["ranks"] == 2 and hh["pairs_per_call_per_rank"] == 16 and hh["identical_to_device_path"] is True
+    assert "without torch" in hh["measured_in"] and hh["value"] > 100
+    assert line["pcie_inclusive"]["ranks"] == 2 and line["speedup_vs_cpu_1thread"] > 1
+    assert "pipeline_frac" not in line["roofline"] and 0 < line["roofline"]["frac"] <= 1

@@ -49,6 +49,52 @@ def one(B, W, H, forest):
     ctx.close()
 
 
+def serve(B, W, H, forest, dev_index, warm=5):
+    """One rank's torch-free host-to-host leg, driven by bench.py over a pipe (bench.py: HostChild): this process holds the
+    library's own ROCm runtime -- the situation of a C++ caller -- while the bench process (torch's bundled runtime) carries
+    the barriers between the ranks.  Protocol, one line each way: after `warm` untimed calls "ready"; per "go" one synchronous
+    gpc_hip_match_batch call, answered with its seconds; "done" -> one JSON record (counts, checksums of three pairs, host
+    description; rank 0 also the single-pair leg) and exit."""
+    import zlib
+    ctx = g.Context(dev_index)
+    ctx.load_forest(forest, W, H)
+    s = g.Settings.sparsematch()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    L, R = synth_batch(W, H, [rank + world * j for j in range(B)])   # this rank's shard: pair i -> rank i mod N
+    cap = 300000
+    Lp, Rp = ctx.pinned_empty(L.shape, np.uint8), ctx.pinned_empty(R.shape, np.uint8)
+    Lp[:] = L
+    Rp[:] = R
+    out = ctx.pinned_empty((B, cap), g.SUPPORT_DTYPE)
+    st, counts, o = 0, None, None
+    for _ in range(warm):
+        o, counts, ncand, st = ctx.match_batch(Lp, Rp, s, cap, out=out)
+    sys.stdout.write("ready\n")
+    sys.stdout.flush()
+    tt = []
+    for line in sys.stdin:
+        cmd = line.strip()
+        if cmd == "go":
+            t0 = time.perf_counter()
+            o, counts, ncand, st = ctx.match_batch(Lp, Rp, s, cap, out=out)
+            dt = time.perf_counter() - t0
+            tt.append(dt)
+            sys.stdout.write("%.9f\n" % dt)
+            sys.stdout.flush()
+        elif cmd == "done":
+            break
+    rec = {"status": int(st), "calls": len(tt), "pairs_per_call": B, "host_buffers": "page-locked (gpc_hip_host_alloc)",
+           "bytes_in": int(L.nbytes + R.nbytes), "bytes_over_the_link_out": int(counts.sum()) * 4 + B * H * 4,
+           "bytes_delivered": int(counts.sum()) * 12, "counts": [int(v) for v in counts],
+           "crc32": {str(j): zlib.crc32(o[j, : int(counts[j])].tobytes()) for j in sorted(set((0, B // 2, B - 1)))},
+           "host": host_info(ctx)}
+    if rank == 0 and not os.environ.get("GPC_BENCH_NO_SINGLE"):
+        rec["single_pair_host_to_host"] = single_pair(ctx, W, H, s)
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    ctx.close()
+
+
 def host_info(ctx):
     """What the host side of the call had to work with (the expansion of packed records is CPU work)."""
     model = ""
@@ -101,6 +147,8 @@ def single_pair(ctx, W, H, s):
 def main():
     if len(sys.argv) >= 2 and sys.argv[1] == "--one":
         return one(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+    if len(sys.argv) >= 2 and sys.argv[1] == "--serve":
+        return serve(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]))
     W, H = 1024, 436
     ctx = g.Context(0)
     ctx.load_forest(os.path.join(ROOT, "forests", "defaultZeroForest.txt"), W, H)
