@@ -114,9 +114,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // Exclusive scan of arr[0 .. NT*SPT) in place by an NT-thread workgroup (thread t owns SPT
-// consecutive counters); arr[NT*SPT] receives the total.  s_w: NT/64 words of scratch.
+// consecutive counters); arr[NT*SPT] receives the total (TOTAL).  s_w: NT/64 words of scratch.
 // Ends with a barrier.
-template <int SPT, int NT = 256>
+template <int SPT, int NT = 256, bool TOTAL = true>
 __device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_t* __restrict__ s_w, int tid) {
   // (opaque: inside a row loop the addresses derived from tid are loop-invariant; hoisted at 64 VGPRs they are spilled to
   // scratch, and a scratch reload waits for every vector-memory operation the wave has in flight)
@@ -141,6 +141,6 @@ __device__ __forceinline__ void block_exscan(uint32_t* __restrict__ arr, uint32_
     arr[tid * SPT + i] = base;
     base += v[i];
   }
-  if (tid == NT - 1) arr[NT * SPT] = base;
+  if (TOTAL && tid == NT - 1) arr[NT * SPT] = base;
   __syncthreads();
 }

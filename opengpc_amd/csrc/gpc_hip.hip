@@ -31,6 +31,7 @@
 #include "k_partition.h"
 #include "k_preprocess.h"
 #include "k_rowjoin.h"
+#include "k_rowjoin_fused.h"
 #include "k_rows.h"
 #include "k_train.h"
 
@@ -644,8 +645,6 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
   // S >= NT*SPT because the rank phase reuses the key table as bucket counters
   p.log2s = 1;
   while ((1 << p.log2s) < p.nt * p.spt || ((1 << p.log2s) < 2 * (W - 2 * GPC_R) && p.log2s < 14)) ++p.log2s;
-  // the fused join keeps the matched codes of its rank phase in the upper half of the (then dead) key table: S >= 2 * NT*SPT
-  while (!c->no_fuse && p.spt <= 4 && (1 << p.log2s) < 2 * p.nt * p.spt && p.log2s < 14) ++p.log2s;
   p.lds = ((size_t)8 * ((1u << p.log2s) + 1) + 15) / 16 * 16;  // keys + flag/x words
   return p;
 }
@@ -715,11 +714,10 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     if (apply_filter && s->vertical_tolerance < 0) disp_high = -1;
     const JoinPlan jp = plan_join(c, W);
     if (jp.nt * jp.spt < W) return GPC_E_UNSUPPORTED;  // unreachable below check_dims' 16384 px
-    // One launch for join + output (k_rowjoin.h, FUSE) where the table leaves room for the ranked words (rows up to
-    // 8192 px) and the records' place follows from the rows before them alone (not the gap-free packing of `totals`)
-    // keys [S+4 words] | 16-bit flags [S/2 words] | pending row's ranked words [NT*SPT]
-    const size_t flds = (size_t)4 * ((1u << jp.log2s) + 4) + (size_t)2 * (1u << jp.log2s) + (size_t)4 * jp.nt * jp.spt;
-    bool fuse = !c->no_fuse && npairs >= c->fuse_min_pairs && jp.spt <= 4 && (1 << jp.log2s) >= 2 * jp.nt * jp.spt &&
+    // One launch for join + output (k_rowjoin_fused.h) for rows up to 4096 px (12 bits of x beside the flags) when the
+    // records' place follows from the rows before them alone (not the gap-free packing of `totals`)
+    const size_t flds = RJF_LDS_BYTES(jp.nt * jp.spt);
+    bool fuse = !c->no_fuse && npairs >= c->fuse_min_pairs && jp.spt <= 4 && jp.nt * jp.spt <= 4096 &&
                 !(po && po->totals) && (long)npairs * (H - 2 * GPC_R) < (1l << 31) - 65536;
     if (fuse && !c->fuse_always) {
       // The persistent launch pays off once every workgroup takes several rows (its output lags one row behind, and the
@@ -727,63 +725,90 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
       // 1024x436: 1 .. 24 pairs 3-10 % slower, 32 pairs even, 48 .. 256 pairs 4-11 % faster; 1920x1080: one pair 6 % slower,
       // 8 pairs 8 % faster; one 3840x2160 pair 9 % faster.  Rows per resident workgroup >= 6, or >= 3 for rows of
       // 2048 px and more, is where it wins.
-      const long lds_wgs = (long)(160 * 1024 / (flds + 256)), wave_wgs = 32 / (jp.nt / 64);
+      const long lds_wgs = (long)(160 * 1024 / (flds + 64)), wave_wgs = 32 / (jp.nt / 64);
       const long resident = (long)c->num_cus * (lds_wgs < wave_wgs ? lds_wgs : wave_wgs);
       const long rows_total = (long)npairs * (H - 2 * GPC_R);
       fuse = rows_total >= 6 * resident || (W >= 2048 && rows_total >= 3 * resident);
     }
     if (fuse) {
+      // k_row_join_fused (k_rowjoin_fused.h): one by-value parameter the kernel reads from its argument segment
       const int nrows = H - 2 * GPC_R;
+      CHK(check_join_err(c));  // a look-back of an EARLIER launch that timed out is reported before anything new is queued
       CHK(ensure_join_state(c, (size_t)npairs * nrows));
-      gpc::RjFuse f;
-      f.tickets = (uint32_t*)c->jstate.p;
-      f.status = (unsigned long long*)((uint32_t*)c->jstate.p + RJ_SHARDS * RJ_TICKET_STRIDE);
-      f.err = c->d_err;
-      f.epoch = ++c->join_epoch;
-      f.npairs = npairs;
-      f.nshards = npairs < c->fuse_shards ? npairs : c->fuse_shards;
-      f.mode = mode;
-      f.out = d_out;
-      f.cap = cap;
-      f.counts = d_counts;
-      f.ncand = d_ncand;
-      f.rows_out = po ? po->rows : nullptr;
-      f.packed_stride = po ? po->packed_stride : 0l;
-      f.rows_stride = po ? po->rows_stride : 0l;
+      const size_t lds = flds;
+      gpc::RjfArgs a;
+      memset(&a, 0, sizeof a);
+      a.codes = (const uint32_t*)c->codes.p;
+      a.cand = d_cand;
+      a.img_stats = (const int32_t*)c->stats.p;
+      a.tickets = (uint32_t*)c->jstate.p;
+      a.status = (unsigned long long*)((uint32_t*)c->jstate.p + RJ_SHARDS * RJ_TICKET_STRIDE);
+      a.err = c->d_err;
+      a.out = d_out;
+      a.counts = d_counts;
+      a.ncand = d_ncand;
+      a.rows_out = po ? po->rows : nullptr;
+      a.packed_stride = po ? po->packed_stride : 0l;
+      a.rows_stride = po ? po->rows_stride : 0l;
+      a.W = W;
+      a.H = H;
+      a.disp_high = disp_high;
+      a.apply_filter = apply_filter;
+      a.epoch = ++c->join_epoch;
+      a.npairs = npairs;
+      a.mode = mode;
+      a.cap = cap;
       Timed t(c, KID_ROW_JOIN);
       const bool wide = wide_codes(c);
-      snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join<%d, %d, %s, false, true>", jp.spt, jp.nt,
+      snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join_fused<%d, %d, %s>", jp.spt, jp.nt,
                wide ? "true" : "false");
       c->launch_name[KID_GATHER_ROWS][0] = 0;
-#define LAUNCH_FJOIN(SPT, NT, WIDE)                                                                             \
+#define LAUNCH_RJF(SPT, NT, WIDE)                                                                               \
   do {                                                                                                          \
-    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join<SPT, NT, WIDE, false, true>);               \
-    int& per_cu = c->wgs_per_cu[std::make_pair(fn_, flds)];                                                     \
+    const void* fn_ = reinterpret_cast<const void*>(gpc::k_row_join_fused<SPT, NT, WIDE>);                      \
+    int& per_cu = c->wgs_per_cu[std::make_pair(fn_, lds)];                                                      \
     if (per_cu == 0) {                                                                                          \
-      if (flds > 48 * 1024) CHK(allow_dyn_lds(c, fn_, flds));                                                   \
-      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_, NT, flds));                          \
+      if (lds > 48 * 1024) CHK(allow_dyn_lds(c, fn_, lds));                                                     \
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_, NT, lds));                           \
       if (per_cu < 1) per_cu = 1;                                                                               \
     }                                                                                                           \
     long nwg = c->fuse_wgs > 0 ? c->fuse_wgs : (long)per_cu * c->num_cus;                                       \
     if (nwg > (long)npairs * nrows) nwg = (long)npairs * nrows;                                                 \
-    hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE, false, true>), dim3((unsigned)nwg), dim3(NT), flds, c->stream, \
-                       (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                      \
-                       (const int32_t*)c->stats.p, (uint32_t*)nullptr, (int32_t*)nullptr, jp.log2s, 1,          \
-                       gpc::RjVirt(), f);                                                                       \
+    /* every shard needs a workgroup that draws its tickets (workgroup b serves shard b % nshards) */           \
+    int nsh = npairs < c->fuse_shards ? npairs : c->fuse_shards;                                                \
+    if (nsh > nwg) nsh = (int)nwg;                                                                              \
+    a.nshards = nsh;                                                                                            \
+    if (getenv("GPC_HIP_DEBUG")) fprintf(stderr, "[gpc_hip] k_row_join_fused<%d, %d>: %d workgroups per CU by the occupancy API, %ld workgroups, %d shards, %zu B of LDS\n", SPT, NT, per_cu, nwg, nsh, lds); \
+    a.n_hi = npairs % nsh;                                                                                      \
+    a.ps[0] = npairs / nsh + (a.n_hi ? 1 : 0);                                                                  \
+    a.ps[1] = npairs / nsh;                                                                                     \
+    for (int k_ = 0; k_ < 2; ++k_) {                                                                            \
+      const GpcDivW dv_ = make_divw(a.ps[k_] > 1 ? a.ps[k_] : 2);                                     \
+      a.ps_magic[k_] = dv_.magic;                                                                               \
+      a.ps_sh[k_] = dv_.sh;                                                                                     \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gpc::k_row_join_fused<SPT, NT, WIDE>), dim3((unsigned)nwg), dim3(NT), lds, c->stream, a); \
   } while (0)
-#define LAUNCH_FJOIN_W(SPT, NT) do { if (wide) LAUNCH_FJOIN(SPT, NT, true); else LAUNCH_FJOIN(SPT, NT, false); } while (0)
-#define LAUNCH_FJOIN_S(NT)                      \
-  switch (jp.spt) {                             \
-    case 1: LAUNCH_FJOIN_W(1, NT); break;       \
-    case 2: LAUNCH_FJOIN_W(2, NT); break;       \
-    default: LAUNCH_FJOIN_W(4, NT); break;      \
+#define LAUNCH_RJF_W(SPT, NT) do { if (wide) LAUNCH_RJF(SPT, NT, true); else LAUNCH_RJF(SPT, NT, false); } while (0)
+#define LAUNCH_RJF_S(NT)                      \
+  switch (jp.spt) {                           \
+    case 1: LAUNCH_RJF_W(1, NT); break;       \
+    case 2: LAUNCH_RJF_W(2, NT); break;       \
+    default: LAUNCH_RJF_W(4, NT); break;      \
   }
-      if (jp.nt == 1024) { LAUNCH_FJOIN_S(1024) }
-      else if (jp.nt == 512) { LAUNCH_FJOIN_S(512) }
-      else { LAUNCH_FJOIN_S(256) }
-#undef LAUNCH_FJOIN_S
-#undef LAUNCH_FJOIN_W
-#undef LAUNCH_FJOIN
+      if (getenv("GPC_HIP_SPT3") && jp.nt == 256 && W <= 768 && !wide) {   // (experiment: what a pixel slot per thread costs)
+        const int nb3 = 768;
+        const size_t lds3 = RJF_LDS_BYTES(nb3);
+#define lds lds3
+        LAUNCH_RJF(3, 256, false);
+#undef lds
+      } else
+      if (jp.nt == 1024) { LAUNCH_RJF_S(1024) }
+      else if (jp.nt == 512) { LAUNCH_RJF_S(512) }
+      else { LAUNCH_RJF_S(256) }
+#undef LAUNCH_RJF_S
+#undef LAUNCH_RJF_W
+#undef LAUNCH_RJF
       HIPCHK(c, hipGetLastError());
       return GPC_OK;
     }
@@ -801,7 +826,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     hipLaunchKernelGGL((gpc::k_row_join<SPT, NT, WIDE>), jgrid, dim3(NT), jp.lds, c->stream,                  \
                        (const uint32_t*)c->codes.p, d_cand, W, H, disp_high, apply_filter,                    \
                        (const int32_t*)c->stats.p, (uint32_t*)c->staged.p, (int32_t*)c->rowcnt.p, jp.log2s,   \
-                       rpw, gpc::RjVirt(), gpc::RjFuse());                                                    \
+                       rpw, gpc::RjVirt());                                                    \
   } while (0)
 #define LAUNCH_JOIN_W(SPT, NT) do { if (wide) LAUNCH_JOIN(SPT, NT, true); else LAUNCH_JOIN(SPT, NT, false); } while (0)
 #define LAUNCH_JOIN_S(NT)                      \
@@ -1019,7 +1044,7 @@ int run_partition_match(gpc_hip_ctx* c, const GlobalPlan& g, int W, int H, int n
     CHK(allow_dyn_lds(c, fn_, lds));                                                                                    \
     hipLaunchKernelGGL((gpc::k_row_join<SPT, 1024, WIDE, true>), jgrid_, dim3(1024), lds, STREAM, (const uint32_t*)nullptr, \
                        (const uint8_t*)nullptr, W, H, s->disp_high, apply_filter, (const int32_t*)nullptr,              \
-                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v, gpc::RjFuse());                              \
+                       (uint32_t*)nullptr, (int32_t*)nullptr, log2s, 1, v);                                             \
   } while (0)
     if (big_bins) {
       // The few over-large partitions first, on a stream of their own: their 8192-record workgroups (one per CU, 44-48 us

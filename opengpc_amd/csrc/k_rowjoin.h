@@ -170,124 +170,8 @@ struct RjVirt {
                           // the few bins that are large by themselves go to the 8192-slot instantiation, the rest to the 4096 one
 };
 
-// FUSE (epipolar rows only): the kernel also does what k_gather_rows did -- it writes the row's supports straight to
-// their final place in the caller's array, in row order.  The place of a row is the number of supports of the rows
-// before it, which is only known while the launch runs, so:
-//   * rows are HANDED OUT, not mapped to block indices: the grid is as many workgroups as the device holds at once
-//     (persistent), and a workgroup draws its next row from a ticket counter (one per shard of pairs; agent-scope
-//     atomic add, requested one row ahead so that its latency is never waited for).  Ticket g of a shard of Ps pairs
-//     is row g / Ps of the shard's pair g % Ps: every earlier row of a pair has a smaller ticket, so whoever holds it
-//     is running (or done) -- waiting for its count cannot deadlock, whatever order the hardware starts workgroups in;
-//   * a row publishes its support count as soon as it knows it, and its inclusive prefix as soon as it knows that
-//     (decoupled look-back, Merrill & Garland): one 8-byte granule {epoch << 2 | state, value} per row, written by one
-//     agent-scope store and polled with agent-scope loads by ONE wave (MI355X_MICROARCH.md, "R2": the data is the flag).
-//     The look-back is bounded: a poll that never matches sets a host-visible error word and the row goes on (the
-//     host then reports GPC_E_HIP) -- every wave of the grid reaches its exit whatever happens;
-//   * matches go to their rank in an LDS array (D) first and leave as whole 12-byte records, consecutive lanes writing
-//     consecutive records;
-//   * the output of a row is DEFERRED by one row of its workgroup: the rows of a pair that are in flight together
-//     (workgroups per shard / Ps: 8 at 256 pairs of 1024x436) reach their counts within a microsecond or two of each
-//     other, and a poll of another workgroup's granule costs 2-3 us under load -- resolving the look-back inside the
-//     row put that wait on every row's critical path (join 512 -> 700 us per 256 pairs, as slow as the two launches).
-//     So row n asks for its predecessors' granules at the top of row n+1, looks at the answer after row n+1's decide
-//     phase -- a whole row time after its own count went out -- and writes row n's records then, while D is idle.
-// LDS of a fused workgroup: keys [S+4 words] | 16-bit flag words [S/2] | D [NT*SPT]: with 12 flag-free bits for a
-// right record's x (rows up to 4096 px) two slots share a flag word, which makes room for D at eight workgroups per CU.
-#define RJ_SHARDS 64               // at most; the host takes 16 (GPC_HIP_FUSE_SHARDS)
-#define RJ_TICKET_STRIDE 32        // words between the shards' counters: one 128-byte line each
-#define RJ_ST_AGG 1u               // granule holds the row's own support count
-#define RJ_ST_PREFIX 2u            // granule holds the supports of this row and all rows before it
-#define RJ_SPIN_LIMIT (1 << 18)    // polls of one look-back window before the row gives up (~0.3 s)
-struct RjFuse {
-  uint32_t* tickets;            // [RJ_SHARDS * RJ_TICKET_STRIDE]: draw counters, zero between launches (the last draw resets)
-  unsigned long long* status;   // [npairs][H - 26]: look-back granules
-  int32_t* err;                 // host-visible word, set when a look-back timed out
-  uint32_t epoch;               // tag of this launch's granules (never 0; the host counts launches)
-  int npairs, nshards;
-  int mode;                     // 0: gpc_support, 1: gpc_correspondence, 2: packed words + row counts (k_rows.h)
-  void* out;
-  int cap;
-  int32_t* counts;              // [npairs]
-  int32_t* ncand;               // [npairs][2] or null
-  int32_t* rows_out;            // mode 2: [npairs][rows_stride]
-  long packed_stride, rows_stride;
-};
-
-__device__ __forceinline__ unsigned long long rj_granule(uint32_t epoch, uint32_t state, uint32_t value) {
-  return ((unsigned long long)((epoch << 2) | state) << 32) | value;
-}
-
-// First window of the look-back of row t (st = its granule): lane l asks for row t-1-l; "rows" before the first hold
-// a prefix of 0.  Executed by one whole wave; the answer is consumed by rj_lookback.
-__device__ __forceinline__ unsigned long long rj_lookback_ask(const unsigned long long* st, int t, int lane, uint32_t epoch) {
-  unsigned long long g = rj_granule(epoch, RJ_ST_PREFIX, 0u);
-#ifdef RJ_DBG_NOLB
-  return g;
-#endif
-  // row0 = granule of the pair's first row (uniform): one scalar base + a 32-bit lane offset
-  const unsigned long long* row0 = st - t;
-  if (t - 1 - lane >= 0)
-    g = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(row0) + (uint32_t)(t - 1 - lane) * 8u),
-                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return g;
-}
-
-// Supports of the pair's rows before row t (one whole wave; every lane gets the result).  g = rj_lookback_ask's answer.
-// Counts are added up to the nearest published prefix; a window in which a row in front of that prefix has not
-// published yet is asked for again (bounded: then *err is set and the sum so far returned).  Beyond the first window
-// -- few pairs in flight: hundreds of rows of one pair run together and the nearest prefix is that far back --
-// RJ_LB_WINDOWS windows are asked for at a time, so that a round trip covers 256 rows.
-#define RJ_LB_WINDOWS 4
-__device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, int t, int lane, uint32_t epoch,
-                                                unsigned long long g, int32_t* err) {
-  uint32_t base = 0u;
-#ifdef RJ_DBG_NOLB
-  return 0u;
-#endif
-  int pos = t - 1, spin = 0;  // wave-uniform: the row lane 0 of the next window looks at
-#ifdef RJ_DBG_COUNT
-  if (lane == 0) atomicAdd(err + 1, 1);  // [1] look-backs
-#endif
-  // one window: adds what it can; returns 1 when the prefix was reached, 0 when the window was all counts, -1 when a
-  // row in front of the nearest prefix has not published yet
-  auto window = [&](unsigned long long gv) -> int {
-    const uint32_t tag = (uint32_t)(gv >> 32);
-    const bool ready = (tag >> 2) == epoch;
-    const unsigned long long notyet = __ballot(!ready);
-    const unsigned long long pfx = __ballot(ready && (tag & 3u) == RJ_ST_PREFIX);
-    const int first_n = notyet ? __ffsll((long long)notyet) - 1 : 64;
-    const int first_p = pfx ? __ffsll((long long)pfx) - 1 : 64;
-    if (first_n < first_p) return -1;
-    uint32_t c = (lane <= first_p) ? (uint32_t)gv : 0u;  // counts of the rows in front of the prefix, and the prefix
-    c = wave_incl_scan(c);
-    base += (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
-    return first_p < 64 ? 1 : 0;
-  };
-  int r = window(g);
-  if (r == 0) pos -= 64;
-  while (r != 1) {
-    if (r < 0) {
-#ifdef RJ_DBG_COUNT
-      if (lane == 0) atomicAdd(err + 2, 1);  // [2] windows with a row that had not published
-#endif
-      if (++spin > RJ_SPIN_LIMIT) {
-        if (lane == 0) atomicOr(err, 1);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    unsigned long long gw[RJ_LB_WINDOWS];
-#pragma unroll
-    for (int k = 0; k < RJ_LB_WINDOWS; ++k) gw[k] = rj_lookback_ask(st - (t - 1 - (pos - 64 * k)), pos - 64 * k + 1, lane, epoch);
-#pragma unroll
-    for (int k = 0; k < RJ_LB_WINDOWS; ++k) {
-      r = window(gw[k]);
-      if (r != 0) break;  // done, or a row of this window has to be waited for
-      pos -= 64;
-    }
-  }
-  return base;
-}
+// (The persistent variant that also writes the supports -- join + output in one launch -- is a kernel of its own:
+// k_rowjoin_fused.h.)
 
 // codes:   [npairs*2][H][W]   (image 2p = left, 2p+1 = right)
 // cand:    [npairs*2][H][W]   candidate bytes (grad, or the caller's scattered mask): WIDE only
@@ -299,78 +183,17 @@ __device__ __forceinline__ uint32_t rj_lookback(const unsigned long long* st, in
 // dynamic LDS: 8*(S+1) bytes  (16 KiB for W = 1024: 8 workgroups per CU = 32 waves, 64 VGPRs)
 // Wide rows use more threads per row before more pixel slots per thread, so that the one
 // or two workgroups that fit a CU (98 KiB of table at W = 3840) still fill its SIMDs.
-// The cnt ranked words (xL | xR << 16) of row y of `pair` leave as records base .. base + cnt - 1 of the pair's array.
-// The kernel's own arguments as they lie in the kernel-argument segment (HIP lays the parameters out in order, each at its
-// natural alignment): rj_out_args() reads the OUTPUT parameters of RjFuse from there at their point of use.  As by-value
-// arguments they were loaded once, kept for the whole persistent kernel and -- at 80 SGPRs for eight waves per SIMD --
-// spilled to VGPR lanes: eight v_readlane per row and wave to get them back, where one s_load_dwordx8 does it now.
-struct RjKernargs {
-  const uint32_t* codes; const uint8_t* cand; int W, H, disp_high, apply_filter; const int32_t* img_stats; uint32_t* staged;
-  int32_t* rowcnt; int log2s, rpw; RjVirt v; RjFuse f;
-};
-struct RjOutArgs { int mode; void* out; int cap; int32_t* counts; int32_t* ncand; int32_t* rows_out; long packed_stride, rows_stride; };
-__device__ __forceinline__ RjOutArgs rj_out_args() {
-  typedef const char __attribute__((address_space(4))) kchar;
-  kchar* p = (kchar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RjKernargs, f);
-  asm volatile("" : "+s"(p));  // (opaque: a load through it is made where it is used, not hoisted to the kernel's top)
-  const RjFuse __attribute__((address_space(4)))* f = (const RjFuse __attribute__((address_space(4)))*)p;
-  RjOutArgs o;
-  o.mode = f->mode; o.out = f->out; o.cap = f->cap; o.counts = f->counts; o.ncand = f->ncand; o.rows_out = f->rows_out;
-  o.packed_stride = f->packed_stride; o.rows_stride = f->rows_stride;
-  return o;
-}
-
-template <int NT>
-__device__ __forceinline__ void rj_emit_row(const RjOutArgs& f, const uint32_t* __restrict__ words, uint32_t cnt, uint32_t base,
-                                            int pair, int y, int tid) {
-#ifdef RJ_DBG_NOEMIT
-  return;
-#endif
-  // (opaque: the per-lane LDS address of words[tid] is loop-invariant, and hoisted out of the row loop it is spilled to
-  // scratch -- whose reload waits for every vector-memory operation of the wave, the ticket draw in flight included)
-  asm volatile("" : "+v"(tid));
-  if (f.mode == 0) {
-    struct __attribute__((packed, aligned(4))) Rec3 { uint32_t x, y, d; };
-    Rec3* o = reinterpret_cast<Rec3*>(f.out) + (long)pair * f.cap;
-    for (uint32_t i = tid; i < cnt; i += NT) {
-      const uint32_t w = words[i], p = base + i;
-      const int xl = (int)(w & 0xFFFFu), xr = (int)(w >> 16);
-      if (p < (uint32_t)f.cap) o[p] = Rec3{(uint32_t)xl, (uint32_t)y, __float_as_uint((float)(xl - xr))};
-    }
-  } else if (f.mode == 2) {
-    uint32_t* o = reinterpret_cast<uint32_t*>(f.out) + pair * f.packed_stride;
-    for (uint32_t i = tid; i < cnt; i += NT) {
-      const uint32_t p = base + i;
-      if (p < (uint32_t)f.cap) o[p] = words[i];
-    }
-    if (tid == 0) f.rows_out[pair * f.rows_stride + y] = (int32_t)cnt;
-  } else {
-    int4* o = reinterpret_cast<int4*>(f.out) + (long)pair * f.cap;
-    for (uint32_t i = tid; i < cnt; i += NT) {
-      const uint32_t w = words[i], p = base + i;
-      if (p < (uint32_t)f.cap) o[p] = make_int4((int)(w & 0xFFFFu), y, (int)(w >> 16), y);
-    }
-  }
-}
-
-// FUSE: grid (workgroups the device holds at once); NT*SPT <= 4096 (12 bits of x beside the flags); the host
-//       guarantees S >= 2 * NB (the rank phase keeps the matched codes in the upper half of the dead key table) and
-//       npairs * (H - 26) < 2^31.  dynamic LDS: 4*(S+4) + 2*S + 4*NT*SPT bytes
-template <int SPT, int NT, bool WIDE, bool VIRT = false, bool FUSE = false>
+template <int SPT, int NT, bool WIDE, bool VIRT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, NT>::kWaves, 8))) void k_row_join(
     const uint32_t* __restrict__ codes, const uint8_t* __restrict__ cand, int W, int H, int disp_high, int apply_filter,
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
-    int log2s, int rpw, RjVirt v, RjFuse f) {
-  static_assert(!(FUSE && VIRT), "the fused output is for image rows");
+    int log2s, int rpw, RjVirt v) {
 #ifndef RJ_KEEP_RPW
   rpw = 1;  // (rows per workgroup with next-row prefetch measured within the noise of one row, DESIGN.md 7, and its eight
             // prefetch registers put scratch into the 1024-thread instantiation: one row per workgroup it is)
 #endif
-  static_assert(!(FUSE && NT * SPT > 4096), "16-bit flag words hold 12 bits of x");
-  // flags of a table slot; FUSE: halfwords, two slots per word, x in the low 12 bits
-  constexpr uint32_t F_LSEEN = FUSE ? 0x1000u : RJ_LSEEN, F_LDUP = FUSE ? 0x2000u : RJ_LDUP;
-  constexpr uint32_t F_RSEEN = FUSE ? 0x4000u : RJ_RSEEN, F_RDUP = FUSE ? 0x8000u : RJ_RDUP;
-  constexpr uint32_t F_XMASK = FUSE ? 0x0FFFu : 0xFFFFu;
+  // flags of a table slot (one word per slot, x of a right record in the low half)
+  constexpr uint32_t F_LSEEN = RJ_LSEEN, F_LDUP = RJ_LDUP, F_RSEEN = RJ_RSEEN, F_RDUP = RJ_RDUP, F_XMASK = 0xFFFFu;
   constexpr int NB = NT * SPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t rj_lds[];
   __shared__ uint32_t s_max_key;
@@ -381,30 +204,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   __shared__ uint32_t s_w[NT / 64];
   __shared__ uint32_t s_cmin, s_cmax;      // smallest / largest matched code of the row: the rank buckets span that range
   __shared__ unsigned s_tail_xv, s_sp_xv;  // VIRT: position of the tail / key-less right record with the smallest pixel index
-  __shared__ uint32_t s_ticket, s_base;    // FUSE: the row drawn for this workgroup; supports of the pair's earlier rows
-  __shared__ uint32_t s_cnt;               // FUSE: matches of the row, known right after the decide phase
   const int S = 1 << log2s;
   uint32_t* t_key = rj_lds;               // [S]   stored key = code + 1, 0 = empty
-  uint32_t* t_w = rj_lds + (FUSE ? S + 4 : S + 1);  // [S] (FUSE: [S/2], two slots per word)  per slot: seen / duplicate flags of either side, x of a right record in the low bits
+  uint32_t* t_w = rj_lds + S + 1;         // [S]   per slot: seen / duplicate flags of either side, x of a right record in the low bits
   uint32_t* r_cnt = t_key;                // [NB+1] bucket counters -> starts   (reuses t_key, dead after step 2)
-  uint32_t* r_key = FUSE ? t_key + NB + 1 : t_w;    // [NB]   matched codes, bucket-contiguous (reuses t_w, dead after step 3; FUSE: the key table's upper half)
-  uint32_t* d_words = rj_lds + (S + 4) + S / 2;     // FUSE: [NB] ranked words of the row whose output is pending
+  uint32_t* r_key = t_w;                  // [NB]   matched codes, bucket-contiguous (reuses t_w, dead after step 3)
   // one returning OR on a slot's flag word; returns what the slot held
-  auto mark = [&](uint32_t h, uint32_t val) -> uint32_t {
-    if (FUSE) {
-      const uint32_t sh = (h & 1u) << 4;
-      return (atomicOr(&t_w[h >> 1], val << sh) >> sh) & 0xFFFFu;
-    }
-    return atomicOr(&t_w[h], val);
-  };
-  auto mark_noret = [&](uint32_t h, uint32_t val) {
-    if (FUSE) atomicOr(&t_w[h >> 1], val << ((h & 1u) << 4));
-    else atomicOr(&t_w[h], val);
-  };
+  auto mark = [&](uint32_t h, uint32_t val) -> uint32_t { return atomicOr(&t_w[h], val); };
+  auto mark_noret = [&](uint32_t h, uint32_t val) { atomicOr(&t_w[h], val); };
   const uint32_t keys_lds = (uint32_t)(uintptr_t)t_key;  // low half of the flat address = LDS offset
 
   const int tid = threadIdx.x, lane = tid & 63;
-  int pair = FUSE ? 0 : (int)blockIdx.y;
+  const int pair = (int)blockIdx.y;
   const int hshift = 32 - log2s;
   const uint32_t smask = (uint32_t)S - 1u;
   // VIRT: this workgroup's partition
@@ -430,34 +241,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     vrr = v.kv + pair * v.recs + v.recs / 2 + offr;
   }
   int last_r = 0;
-  if (!FUSE) last_r = VIRT ? vblk[v.o_misc + 2] /* GP_LASTR */ : img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
-  // FUSE: this workgroup's shard of pairs and its ticket counter
-  const int nrows = H - 2 * GPC_R;
-  uint32_t f_ps = 1u, f_end = 0u, f_last = 0u, f_g = 0u, f_nxt = 0u;
-  int f_shard = 0, f_t = 0;
-  uint32_t* f_tk = nullptr;
-  // the row whose records are still in D: its pair, row, ticket row, count
-  int d_pair = 0, d_y = 0, d_t = -1;
-  uint32_t d_cnt = 0u;
-  unsigned long long d_g0 = 0ull;  // first wave: the granules of the pending row's predecessors
-  if (FUSE) {
-    f_shard = (int)(blockIdx.x % (unsigned)f.nshards);
-    f_ps = (uint32_t)((f.npairs - f_shard + f.nshards - 1) / f.nshards);           // pairs of the shard
-    f_end = f_ps * (uint32_t)nrows;                                                  // tickets that are rows
-    f_last = f_end + (gridDim.x - (unsigned)f_shard + (unsigned)f.nshards - 1u) / (unsigned)f.nshards - 1u;  // the last draw
-    // The counter's address goes through an opaque per-lane zero: for an address it can prove uniform the compiler
-    // makes ONE atomic per wave and broadcasts the result with v_readfirstlane -- which waits for it on the spot,
-    // where the draw for the next row is meant to stay in flight for most of this one.
-    f_tk = f.tickets + f_shard * RJ_TICKET_STRIDE;
-    if (tid == 0) {
-      uint32_t opaque0;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
-      s_ticket = __hip_atomic_fetch_add(f_tk + opaque0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    f_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
-  }
-
+  last_r = VIRT ? vblk[v.o_misc + 2] /* GP_LASTR */ : img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
   // A workgroup handles `rpw` consecutive rows; the NEXT row's codes are fetched into registers
   // while the current row is joined, so only the first row's load latency is exposed.
   const int row0 = VIRT ? v_p : GPC_R + blockIdx.x * rpw;
@@ -514,24 +298,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       }
     }
   };
-  if (!FUSE) fetch_row(row0);
+  fetch_row(row0);
 #pragma unroll 1
-  for (int ri = 0; FUSE ? (f_g < f_end) : (ri < rpw && (VIRT ? ri == 0 : row0 + ri < H - GPC_R)); ++ri) {
-  int y = row0 + ri;
-  if (FUSE) {  // ticket -> (pair, row); the row's loads; the draw for the row after (waited for at the end of this one)
-#ifdef RJ_DBG_PAIRMAJOR
-    const uint32_t qq = f_g / (uint32_t)nrows;
-    pair = f_shard + f.nshards * (int)qq;
-    const uint32_t q = f_g - qq * (uint32_t)nrows;
-#else
-    const uint32_t q = f_g / f_ps;
-    pair = f_shard + f.nshards * (int)(f_g - q * f_ps);
-#endif
-    f_t = (int)q;
-    y = GPC_R + f_t;
-    last_r = img_stats[(pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_LASTROW];
-    fetch_row(y);
-  }
+  for (int ri = 0; ri < rpw && (VIRT ? ri == 0 : row0 + ri < H - GPC_R); ++ri) {
+  const int y = row0 + ri;
   RJ_STAMP_INIT();
 #ifdef RJ_DBG_PADVALU  // calibration: how much of a row's time is VALU issue?  RJ_DBG_PADVALU x 8 dependent-free adds per wave and row
   {
@@ -572,7 +342,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       spl = nspl;
       spr = nspr;
     }
-    if (!VIRT && !FUSE && ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
+    if (!VIRT && ri + 1 < rpw && y + 1 < H - GPC_R) fetch_row(y + 1);
     {  // 16-byte stores; the host rounds the allocation up to a multiple of 16 bytes
       uint4* z = reinterpret_cast<uint4*>(rj_lds);
       // the zeros are made HERE: as a plain constant the compiler keeps them in four registers across the whole row
@@ -580,7 +350,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       uint32_t z0;
       asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
       const uint4 zero = make_uint4(z0, z0, z0, z0);
-      const int nclear = FUSE ? (S + 4 + S / 2) / 4 : (8 * (S + 1) + 15) / 16;  // FUSE: keys + halfword flags; D is not cleared
+      const int nclear = (8 * (S + 1) + 15) / 16;
 #ifndef RJ_DBG_NOCLEAR   // (experiment, with RJ_DBG_EMPTY only: what the table clear costs)
       for (int i = tid; i < nclear; i += NT) z[i] = zero;
 #endif
@@ -595,7 +365,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       s_max_key = c0;
       s_tail_cnt = (int)c0;
       s_tail_minx = c1;
-      if (FUSE) s_cnt = c0;
       if (WIDE) {
         s_sp_l = (int)c0;
         s_sp_r = (int)c0;
@@ -648,14 +417,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(1);
-  // FUSE: the first wave asks for the granules of the PENDING row's predecessors here and looks at the answer after
-  // the lookup phase (the wave has no other vector-memory operation in flight then: its counter is in order, and a
-  // wait for an older load would wait for this one too).  Who does what is spread over the waves for the same reason:
-  // the first wave asks and publishes, the second draws the tickets.  When to ask was measured (256 pairs, first
-  // windows that still held a row that had not published its count, each costing a blocking poll): during the
-  // pending row's own walk, 1.8 us after its count went out, 33 % -- rows of a pair run 1.25 us apart on average with
-  // more jitter than that; at the top of the next row 18 %; here, after the next row's insert phase, 4 %.
-  if (FUSE && d_t >= 0 && tid < 64) d_g0 = rj_lookback_ask(f.status + (long)d_pair * nrows + d_t, d_t, lane, f.epoch);
   if (WIDE && VIRT && spr) {  // which position holds the key-less right record with the smallest pixel index (read after the next barrier)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
@@ -722,17 +483,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(2);
-  if (FUSE) {  // the pending row's place: supports of the pair's rows before it
-    if (d_t >= 0 && tid < 64) {
-      unsigned long long* d_st = f.status + (long)d_pair * nrows + d_t;
-      const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, d_g0, f.err);
-      if (lane == 0) {
-        if (d_t > 0) __hip_atomic_store(d_st, rj_granule(f.epoch, RJ_ST_PREFIX, base + d_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base = base;
-      }
-    }
-  }
-
   // ---- 3. decide every left candidate; the key table is dead already: it becomes the rank counters
   {  // NB + 1 counters: SPT consecutive ones per thread (16-byte stores where SPT is 4: one LDS instruction instead of five)
     uint32_t z0;
@@ -753,7 +503,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     xr[j] = 0u;
     bool good = false;
     if (kl[j]) {
-      const uint32_t w = FUSE ? (t_w[hl[j] >> 1] >> ((hl[j] & 1u) << 4)) : t_w[hl[j]];
+      const uint32_t w = t_w[hl[j]];
       const bool tail = tail_row && kl[j] == tail_key;
       good = !(w & F_LDUP) && (tail ? (s_tail_cnt == 2) : ((w & (F_RSEEN | F_RDUP)) == F_RSEEN));
       xr[j] = tail ? (VIRT ? s_tail_xv : s_tail_minx) : (w & F_XMASK);
@@ -789,28 +539,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
       }
     }
   }
-  if (FUSE) {  // the row's support count, one LDS add per wave that has a match
-    uint32_t wc = 0u;
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) wc += (uint32_t)__popcll(__ballot((okm >> j) & 1u));
-    if (lane == 0 && wc) atomicAdd(&s_cnt, wc);
-  }
   __syncthreads();  // the flag words are dead from here on: their LDS is reused
   RJ_STAMP(3);
-  // FUSE: this row's count goes out at once (later rows of the pair may be waiting for it)
-  uint32_t f_cnt = 0u;
-  if (FUSE) {
-    f_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt);
-    if (tid == 0)
-      __hip_atomic_store(f.status + (long)pair * nrows + f_t, rj_granule(f.epoch, f_t == 0 ? RJ_ST_PREFIX : RJ_ST_AGG, f_cnt),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 64) {  // the draw for this workgroup's next row: in flight over the rank phase, read at the row's end
-      uint32_t opaque0;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
-      f_nxt = __hip_atomic_fetch_add(f_tk + opaque0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-
   // ---- 4. output position = rank of the code among the row's matches (counting rank)
   // Measured on one box and NOT adopted (546 / 514 us per 256 pairs as it stands):
   //   * matches alone in their bucket written straight from the scan, only shared buckets walked: 553 us;
@@ -844,38 +574,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
   }
   __syncthreads();
   RJ_STAMP(4);
-  if (FUSE && d_t >= 0) {  // the pending row's records leave (D is rewritten by this row's walk, two barriers on)
-    const uint32_t base = s_base;
-    const RjOutArgs fo = rj_out_args();
-    rj_emit_row<NT>(fo, d_words, d_cnt, base, d_pair, d_y, tid);
-    if (d_t == nrows - 1 && tid == 0) {  // the pair's last row knows the total
-      fo.counts[d_pair] = (int32_t)(base + d_cnt);
-      if (fo.ncand) {
-        fo.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-        fo.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-      }
-    }
-  }
+#ifndef RJ_OLD_RANK
+  // How many matches share the bucket, read BEFORE the scan turns the counters into starts (every such read is done
+  // before block_exscan's first barrier, the scan's stores come after it): four matches in five are alone in theirs and
+  // need neither a place in r_key nor the two reads of neighbouring starts -- their rank is their bucket's start.
+  // rs[j] becomes (arrival order | bucket count << 16): both are at most NB <= 4096... 16384 (VIRT) < 2^16.
+#pragma unroll
+  for (int j = 0; j < SPT; ++j)
+    if ((okm >> j) & 1u) rs[j] |= r_cnt[rb[j]] << 16;
+#endif
 #ifndef RJ_DBG_NOSCAN    // (experiment, with RJ_DBG_EMPTY only)
   block_exscan<SPT, NT>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b, r_cnt[NB] = number of matches
 #endif
+#ifdef RJ_OLD_RANK
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) r_key[r_cnt[rb[j]] + rs[j]] = kl[j] - 1u;  // the code (WIDE: the key-less 0xFFFFFFFF ranks last)
+#else
+#pragma unroll
+  for (int j = 0; j < SPT; ++j)
+    if ((okm >> j) & 1u) {
+      rb[j] = r_cnt[rb[j]];  // the bucket's first rank (the bucket index is not needed again)
+      if ((rs[j] >> 16) > 1u) r_key[rb[j] + (rs[j] & 0xFFFFu)] = kl[j] - 1u;  // the code (WIDE: the key-less 0xFFFFFFFF ranks last)
+    }
+#endif
   __syncthreads();
   RJ_STAMP(5);
   const long rowbase = (long)pair * H + y;
-  // FUSE: the ranked words wait in D for the row's place in the output
-  uint32_t* dst = FUSE ? d_words : (VIRT ? v.staged + pair * (v.recs / 2) + v_offl : staged + rowbase * W);
+  uint32_t* dst = (VIRT ? v.staged + pair * (v.recs / 2) + v_offl : staged + rowbase * W);
 #pragma unroll
   for (int j = 0; j < SPT; ++j)
     if ((okm >> j) & 1u) {
       // (two plain ds_read_b32: for neighbouring words the compiler emits ds_read2_b32, which issues 3.6 times slower than
       // one ds_read_b32 on gfx950 -- profiles/r03_ubench2_issue_rates.txt -- and it unrolls the walk 16-fold with them)
+#ifdef RJ_OLD_RANK
       uint32_t bidx = rb[j];
       const uint32_t s0 = r_cnt[bidx];
       asm volatile("" : "+v"(bidx));
       const uint32_t e0 = r_cnt[bidx + 1];
+#else
+      const uint32_t s0 = rb[j], e0 = s0 + (rs[j] >> 16);
+#endif
       uint32_t rank = s0;
       const uint32_t cj = kl[j] - 1u;
 #ifdef RJ_WALK_ALWAYS
@@ -896,50 +635,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
         dst[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);
       }
     }
-  if (!FUSE && tid == 0) {
+  if (tid == 0) {
     if (VIRT) vblk[v.o_rowcnt + y] = (int32_t)r_cnt[NB];
     else rowcnt[rowbase] = (int32_t)r_cnt[NB];
-  }
-  if (FUSE) {  // this row is the pending one now
-    d_pair = pair;
-    d_y = y;
-    d_t = f_t;
-    d_cnt = f_cnt;
-    if (tid == 64) s_ticket = f_nxt;
   }
 #ifdef GPC_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RJ_STAMP(6);
   RJ_STAMP_FLUSH();
-  if (FUSE || (ri + 1 < rpw && y + 1 < H - GPC_R)) __syncthreads();  // the table is cleared again for the next row
-  if (FUSE) f_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
+  if (ri + 1 < rpw && y + 1 < H - GPC_R) __syncthreads();  // the table is cleared again for the next row
   }  // rows of this workgroup
-  if (FUSE) {
-    if (tid == 0 && f_g == f_last)  // every workgroup of the shard has drawn its last ticket: the counter starts over
-      __hip_atomic_store(f_tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d_t >= 0) {  // the last row of this workgroup is still pending
-      if (tid < 64) {
-        unsigned long long* d_st = f.status + (long)d_pair * nrows + d_t;
-        const uint32_t base = rj_lookback(d_st, d_t, lane, f.epoch, rj_lookback_ask(d_st, d_t, lane, f.epoch), f.err);
-        if (lane == 0) {
-          if (d_t > 0) __hip_atomic_store(d_st, rj_granule(f.epoch, RJ_ST_PREFIX, base + d_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_base = base;
-        }
-      }
-      __syncthreads();
-      const uint32_t base = s_base;
-      const RjOutArgs fo = rj_out_args();
-      rj_emit_row<NT>(fo, d_words, d_cnt, base, d_pair, d_y, tid);
-      if (d_t == nrows - 1 && tid == 0) {
-        fo.counts[d_pair] = (int32_t)(base + d_cnt);
-        if (fo.ncand) {
-          fo.ncand[d_pair * 2 + 0] = img_stats[(d_pair * 2 + 0) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-          fo.ncand[d_pair * 2 + 1] = img_stats[(d_pair * 2 + 1) * GPC_STAT_STRIDE + GPC_STAT_NCAND];
-        }
-      }
-    }
-  }
 }
 
 }  // namespace gpc
