@@ -106,7 +106,21 @@ struct ContextHolder {
     if (ctx) gpc_hip_destroy(ctx);
   }
 };
+// Status of the last gpc:: call on this thread that reached the library (GPC_OK = 0): the reference's API returns results
+// by value and has no error channel, so a failed call returns an EMPTY result -- which also is what "no matches" looks
+// like.  A pipeline that must tell the two apart asks gpc::inference::lastStatus() / lastError() after the call.
+inline int& last_status() {
+  static thread_local int st = GPC_OK;
+  return st;
+}
+inline std::string& last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
 inline void fail(int st, gpc_hip_ctx* ctx, const char* what) {
+  last_status() = st;
+  last_error() = std::string(what) + " failed: " + gpc_hip_status_string(st) +
+                 ((st == GPC_E_HIP && ctx) ? std::string(" (") + gpc_hip_last_error(ctx) + ")" : std::string());
   std::cout << "gpc_hip: " << what << " failed: " << gpc_hip_status_string(st);
   if (st == GPC_E_HIP && ctx) std::cout << " (" << gpc_hip_last_error(ctx) << ")";
   std::cout << std::endl;
@@ -134,6 +148,15 @@ inline ContextHolder& holder() {
   return h;
 }
 }  // namespace detail
+
+// Extension (the reference has no error channel): status / message of this thread's last failed gpc:: call, GPC_OK (0)
+// and "" when none failed since clearStatus().  An empty result with lastStatus() == 0 means "no matches".
+inline int lastStatus() { return detail::last_status(); }
+inline const std::string& lastError() { return detail::last_error(); }
+inline void clearStatus() {
+  detail::last_status() = GPC_OK;
+  detail::last_error().clear();
+}
 
 class Forest {
  public:
@@ -249,6 +272,8 @@ class Forest {
   std::vector<ndb::Support> matchPair(ndb::Buffer<uint8_t>& simg, ndb::Buffer<uint8_t>& timg, FilterMask& forestmask,
                                       InferenceSettings settings, int* candidatesL = nullptr,
                                       int* candidatesR = nullptr) {
+    if (candidatesL) *candidatesL = 0;  // (defined on every path out, the failing ones included)
+    if (candidatesR) *candidatesR = 0;
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
@@ -282,6 +307,8 @@ class Forest {
     }
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_match_pair");
+      if (candidatesL) *candidatesL = 0;
+      if (candidatesR) *candidatesR = 0;
       return std::vector<ndb::Support>();
     }
     const ndb::Support* res = static_cast<const ndb::Support*>(h.pin_out);

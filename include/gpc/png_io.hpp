@@ -83,7 +83,13 @@ inline int decode_file(const std::string& path, Image& img) {
   if (interlace != 0 || (img.bit_depth != 8 && img.bit_depth != 16)) return 3;
   const size_t bpp = (size_t)img.channels * img.bit_depth / 8;
   const size_t stride = (size_t)img.width * bpp;
-  std::vector<uint8_t> raw((stride + 1) * img.height);
+  // The header's size is checked against the DATA before anything is allocated for it: deflate expands at most 1032 : 1,
+  // so an image the compressed stream cannot possibly fill (a forged or truncated file) is refused here instead of being
+  // given gigabytes; 2^31 bytes of scanlines bounds what an honest one may ask for.
+  if (img.width > (1 << 24) || img.height > (1 << 24)) return 3;
+  const size_t need = (stride + 1) * (size_t)img.height;
+  if (need > ((size_t)1 << 31) || need > (size_t)idat.size() * 1032 + 1024) return 3;
+  std::vector<uint8_t> raw(need);
   uLongf out_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return 3;
   img.pixels.assign(stride * img.height, 0);

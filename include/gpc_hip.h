@@ -163,9 +163,14 @@ int gpc_hip_match_pair(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* raw
  * of what the call queues, not for the stream; part of their work runs on a second stream of the context that
  * is joined back into the context's stream before the call returns.  In either case the outputs may be read
  * only after gpc_hip_synchronize (or another wait on the stream).
- * The join that writes the supports places a row behind the rows before it with a bounded wait on
- * other workgroups; a wait that ran out (not observed so far) is reported by the next
- * gpc_hip_synchronize as GPC_E_HIP and the outputs of that launch must not be used. */
+ * The join that writes the supports (three launches: the last one) places a row behind the rows before it with a
+ * bounded wait on other workgroups; a wait that ran out (not observed so far) makes the kernel store the number of
+ * that launch into a host-visible word, and the outputs of that launch must not be used.  The word is examined by
+ * gpc_hip_synchronize and by every entry point that synchronises itself (they return GPC_E_HIP, gpc_hip_last_error
+ * names the launch), and -- for callers that gave the context their own stream and wait on it themselves -- at the
+ * top of the NEXT call that queues such a join and in gpc_hip_destroy (which then returns GPC_E_HIP after freeing
+ * everything): such callers should call gpc_hip_synchronize once before trusting a batch they did not wait for
+ * through this library. */
 int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const uint8_t* d_rawR,
                                int width, int height, int npairs, const gpc_settings* settings,
                                gpc_support* d_out, int cap_per_pair, int32_t* d_counts,

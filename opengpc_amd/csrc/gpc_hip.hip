@@ -649,8 +649,11 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
   return p;
 }
 
-// A look-back of the fused join gave up (k_rowjoin.h, RJ_SPIN_LIMIT): the results of that launch are not to be used.
-// Called wherever an entry point has just synchronised the stream.
+// A look-back of the fused join gave up (k_rowjoin_fused.h, RJ_SPIN_LIMIT): the results of that launch are not to be
+// used.  The kernel stores the launch's epoch (never 0) into a page-locked word with a plain system-scope store; the word
+// is looked at wherever an entry point has just synchronised the stream, at the top of the NEXT fused launch (callers that
+// wait on their own stream -- set_stream + their own synchronisation -- learn of it there at the latest) and in
+// gpc_hip_destroy, and says WHICH launch failed.
 int check_join_err(gpc_hip_ctx* c) {
 #ifdef RJ_DBG_COUNT
   if (c->h_err && c->h_err[1]) {
@@ -658,10 +661,14 @@ int check_join_err(gpc_hip_ctx* c) {
     c->h_err[1] = c->h_err[2] = c->h_err[3] = 0;
   }
 #endif
-  if (c->h_err && *c->h_err) {
-    *c->h_err = 0;
-    snprintf(c->err, sizeof(c->err), "k_row_join (fused output): a row waited too long for the rows before it");
-    return GPC_E_HIP;
+  if (c->h_err) {
+    const int32_t ep = __atomic_load_n(c->h_err, __ATOMIC_RELAXED);
+    if (ep) {
+      __atomic_store_n(c->h_err, 0, __ATOMIC_RELAXED);
+      snprintf(c->err, sizeof(c->err), "k_row_join_fused: a row waited too long for the rows before it in fused launch %d of this "
+               "context (%u launched so far): that launch's supports are not to be used", ep, c->join_epoch);
+      return GPC_E_HIP;
+    }
   }
   return GPC_OK;
 }
@@ -1476,6 +1483,9 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   if (!c) return GPC_E_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  // a fused-join time-out nobody has asked about (callers that only ever waited on their own stream): say so, once
+  const int pending_err = check_join_err(c);
+  if (pending_err != GPC_OK) fprintf(stderr, "gpc_hip_destroy: %s\n", c->err);
   DevBuf* bufs[] = {&c->raw, &c->smooth, &c->grad, &c->candmap, &c->codes, &c->staged, &c->rowcnt,
                     &c->stats, &c->out, &c->counts, &c->ncand, &c->mask, &c->gkeys[0], &c->gkeys[1],
                     &c->gvals[0], &c->gvals[1], &c->ghist, &c->gmisc, &c->hkeys[0], &c->hkeys[1],
@@ -1509,7 +1519,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
-  return GPC_OK;
+  return pending_err;
 }
 
 const char* gpc_hip_last_error(const gpc_hip_ctx* c) { return c ? c->err : "null context"; }
@@ -1584,8 +1594,10 @@ int gpc_hip_parse_forest(const char* text, int W, int H, gpc_filter_mask* fm) {
         return GPC_E_IO;
       if (fm->num_tests < GPC_MAX_TESTS) {  // inference.hpp:426
         const int t = fm->num_tests++;
-        fm->mask[2 * t] = ix + iy * W;
-        fm->mask[2 * t + 1] = jx + jy * W;
+        // (two's-complement wrap where the reference's int arithmetic overflows -- undefined there; found by UBSan on a
+        // forged file: offsets that large are refused by gpc_hip_set_forest's window check anyway)
+        fm->mask[2 * t] = (int32_t)((uint32_t)ix + (uint32_t)iy * (uint32_t)W);
+        fm->mask[2 * t + 1] = (int32_t)((uint32_t)jx + (uint32_t)jy * (uint32_t)W);
         fm->tau[t] = tau;
       } else {
         fm->discarded++;
@@ -2478,6 +2490,48 @@ int gpc_hip_train_fern(gpc_hip_ctx* c, gpc_hip_train_set* t, int max_depth, cons
 }
 
 // ------------------------------------------------------------------ measurement
+
+// Host-only test hook (tests/cpp/sanitize_host.cpp: AddressSanitizer / UBSan / ThreadSanitizer builds of this file run on
+// the CPU, no device): the expansion pool exactly as gpc_hip_match_batch drives it -- `npairs` pairs of packed records back
+// to back (pair i: counts[i] supports, cut at `cap`; rows[i * hpad + y] of them in row y), every pair split into `parts`
+// row ranges, `threads` workers, landing slots rotating like the chunks' -- plus the copy jobs of the pageable path.
+// Not part of the C ABI (include/gpc_hip.h does not declare it).
+extern "C" int gpc_hip_debug_expand_pool(const uint32_t* packed, const int32_t* rows, int hpad, int H, int npairs,
+                                         const int32_t* counts, int cap, int threads, int parts, gpc_support* out,
+                                         const uint8_t* copy_src, uint8_t* copy_dst, size_t copy_bytes) {
+  if (!packed || !rows || !counts || !out || threads < 1 || parts < 1 || H < 2 * GPC_R + 1) return GPC_E_INVALID;
+  ExpandPool pool;
+  pool.start(threads, nullptr);
+  const uint32_t* recs = packed;
+  for (int i = 0; i < npairs; ++i) {
+    const int32_t* r = rows + (size_t)i * hpad;
+    const long limit = counts[i] < cap ? counts[i] : cap;
+    long first = 0;
+    if ((i & 3) == 3) pool.wait_slot((i + 1) & 3);  // (a landing slot is reused only when its jobs are done)
+    for (int q = 0; q < parts; ++q) {
+      const int y0 = GPC_R + (int)((long)(H - 2 * GPC_R) * q / parts), y1 = GPC_R + (int)((long)(H - 2 * GPC_R) * (q + 1) / parts);
+      if (first < limit && y1 > y0)
+        pool.push(ExpandJob{recs, r, H, y0, y1, (int)first, (int)limit, out + (size_t)i * cap, i & 3});
+      for (int y = y0; y < y1; ++y) first += r[y];
+    }
+    recs += limit;
+  }
+  if (copy_bytes) {
+    const size_t step = (copy_bytes / (size_t)threads + 4095) & ~(size_t)4095;
+    for (size_t at = 0; at < copy_bytes; at += step) {
+      ExpandJob j = {};
+      j.slot = 7;
+      j.copy_src = copy_src + at;
+      j.copy_dst = copy_dst + at;
+      j.copy_bytes = at + step <= copy_bytes ? step : copy_bytes - at;
+      pool.push(j);
+    }
+    pool.wait_slot(7);
+  }
+  pool.wait_all();
+  pool.stop();
+  return GPC_OK;
+}
 
 #ifdef GPC_STAMPS
 // diagnostic build only: read and clear the s_memtime phase sums of k_row_join

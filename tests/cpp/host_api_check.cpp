@@ -111,6 +111,21 @@ int main(int argc, char** argv) {
     printf("API %zu %zu %zu\n", corr.size(), supp.size(), fused.size());
     return 0;
   }
+  // host_api_check nodevice <forest>: matchPair with GPC_HIP_DEVICE pointing at a device that does not exist -- the call must
+  // return an empty result WITH a status (the reference's API has no error channel) and defined candidate counts
+  if (cmd == "nodevice" && argc == 3) {
+    ndb::Buffer<uint8_t> L(64, 96, 7), R(64, 96, 9);
+    gpc::inference::Forest forest;
+    gpc::inference::InferenceSettings st;
+    gpc::inference::Forest::FilterMask fm = forest.readForest(argv[2], L.cols(), L.rows());
+    int cl = -12345, cr = -12345;
+    printf("BEFORE %d [%s]\n", gpc::inference::lastStatus(), gpc::inference::lastError().c_str());
+    std::vector<ndb::Support> r = forest.matchPair(L, R, fm, st, &cl, &cr);
+    printf("AFTER %zu %d %d %d [%s]\n", r.size(), cl, cr, gpc::inference::lastStatus(), gpc::inference::lastError().c_str());
+    gpc::inference::clearStatus();
+    printf("CLEARED %d [%s]\n", gpc::inference::lastStatus(), gpc::inference::lastError().c_str());
+    return 0;
+  }
   if (cmd == "forest" && argc == 5) {
     gpc::inference::Forest f;
     gpc::inference::Forest::FilterMask m = f.readForest(argv[2], atoi(argv[3]), atoi(argv[4]));

@@ -44,6 +44,18 @@ def test_settings_and_pods(check_bin):
     assert "Error opening forest file" in out and "MISSING 0 0 96 64" in out
 
 
+def test_failed_call_leaves_a_status_and_defined_outputs(check_bin, forest_paths):
+    """The reference's API returns by value and has no error channel: a failed call returns an empty result, which is
+    also what "no matches" looks like.  gpc::inference::lastStatus() / lastError() tell them apart, and matchPair's
+    candidate counts are defined on every path out (a device index that does not exist: fails here and on a GPU box)."""
+    env = dict(os.environ, GPC_HIP_DEVICE="9999")
+    out = subprocess.run([check_bin, "nodevice", forest_paths["zero"]], check=True, capture_output=True, text=True, env=env).stdout
+    assert "BEFORE 0 []" in out
+    after = [l for l in out.splitlines() if l.startswith("AFTER")][0].split(" ", 5)
+    assert after[1:4] == ["0", "0", "0"] and int(after[4]) != 0 and "gpc_hip_create failed" in after[5]
+    assert "CLEARED 0 []" in out
+
+
 def test_forest_reader_matches_oracle(check_bin, oracle, forest_paths):
     for name, path in forest_paths.items():
         out = run(check_bin, "forest", path, "1024", "436")
