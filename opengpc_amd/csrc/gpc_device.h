@@ -30,6 +30,7 @@
 #define HT_STRIDE (HT_X + 2 * HT_APRON)  // 288 bytes per LDS row
 #define HT_ROWS (HT_Y + 2 * GPC_R)       // 58 rows
 #define HT_COPY (HT_ROWS * HT_STRIDE)    // bytes of one (shifted) copy of the window
+#define HT_Y_TALL 40                     // the taller tile (k_hash<..., TY>): 66 window rows, 76 KB of LDS, still two workgroups per CU
 
 // Lives in device memory (one copy per arithmetic, gpc_hip_set_forest); the hash kernel reads the
 // fields with scalar loads, so a tap address is `lane base + SGPR`.

@@ -195,7 +195,8 @@ struct gpc_hip_ctx {
   int gp_target = 2000;       // GPC_HIP_GP_TARGET: records per side a partition of the non-epipolar matcher aims at. Per 32 pairs of
                               // 1024x436, join + gather: 1400 -> 208 us, 1800 -> 189, 2000 / 2200 -> 182, 2600 -> 192, 3000 -> 208
   int flat_chunks = 0;        // GPC_HIP_FLAT_CHUNKS: gpc_hip_match_batch with equal chunks only (A/B checks)
-  DevBuf forest_dev;  // [0] = forest, [1] = forest_naive: the hash kernel reads its tests from here (scalar loads)
+  DevBuf forest_dev;  // [0] = forest, [1] = forest_naive, [2] = forest with the tall tile's offsets: the hash kernel reads its tests from here (scalar loads)
+  int hash_tall = -1;  // GPC_HIP_HASH_TALL = 0 | 1: never / always the 40-row tile where it exists (tests, A/B checks); default: by rounds
 
   // fused join + output (k_rowjoin.h, FUSE): ticket counters + look-back granules, launch epoch, error word
   DevBuf jstate;
@@ -560,18 +561,30 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   // vertically adjacent tiles hides the next window's load latency, but the grid must still fill
   // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
   // tiles cover the candidate rows 13 .. H-14 only (k_hash.h)
-  const int gx = (W + HT_X - 1) / HT_X, tiles_y = (H - 2 * GPC_R + HT_Y - 1) / HT_Y;
-#ifndef HT_SLOTS
-#define HT_SLOTS 512   // workgroups of k_hash the device holds at once (2 per CU: 67 KiB of LDS each)
-#endif
+  // the gradient image is k_preprocess's bit image: the batched SSE pipelines (run_preprocess(..., gradbits))
+  const bool gbits = c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive;
+  const int slots = 2 * (c->num_cus > 0 ? c->num_cus : 256);  // workgroups of k_hash the device holds at once (2 per CU: 67-76 KiB of LDS each)
+  const int gx = (W + HT_X - 1) / HT_X;
+  int ty = HT_Y;
+  {
+    // Launches too small for several tiles per workgroup run in ROUNDS of `slots` one-tile workgroups: a single 1920x1080
+    // pair is 8 x 33 x 2 = 528 tiles of 32 rows -- a second round for 16 of them, 39 us of a 74 us step -- and 432 tiles
+    // of 40 rows.  The taller tile (batched SSE pipelines only) is taken where rounds x window rows comes out lower.
+    const long n32 = (long)gx * ((H - 2 * GPC_R + HT_Y - 1) / HT_Y) * nimg, n40 = (long)gx * ((H - 2 * GPC_R + HT_Y_TALL - 1) / HT_Y_TALL) * nimg;
+    const long c32 = (n32 + slots - 1) / slots * (HT_Y + 2 * GPC_R), c40 = (n40 + slots - 1) / slots * (HT_Y_TALL + 2 * GPC_R);
+    if (gbits && n32 < 2l * slots && c40 < c32) ty = HT_Y_TALL;
+    if (gbits && c->hash_tall == 1) ty = HT_Y_TALL;
+    if (c->hash_tall == 0) ty = HT_Y;
+  }
+  const int tiles_y = (H - 2 * GPC_R + ty - 1) / ty;
   int tpw = 1;
-  if ((long)gx * tiles_y * nimg >= 2 * HT_SLOTS) {  // small launches keep one tile per workgroup (parallelism first)
+  if ((long)gx * tiles_y * nimg >= 2l * slots) {  // small launches keep one tile per workgroup (parallelism first)
     double best = 1e30;
     for (int t = 2; t <= 16 && t <= tiles_y; ++t) {
       const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
-      if (nwg < HT_SLOTS) break;
-      const long slots = (nwg + HT_SLOTS - 1) / HT_SLOTS * HT_SLOTS;
-      const double score = (double)(slots - nwg) / (double)slots + ((tiles_y % t) ? 0.04 : 0.0);  // idle tail + ragged split
+      if (nwg < slots) break;
+      const long rounded = (nwg + slots - 1) / slots * slots;
+      const double score = (double)(rounded - nwg) / (double)rounded + ((tiles_y % t) ? 0.04 : 0.0);  // idle tail + ragged split
       if (score < best - 1e-9) { best = score; tpw = t; }
     }
   }
@@ -580,19 +593,20 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
-  snprintf(c->launch_name[KID_HASH], sizeof c->launch_name[0], "gpc::k_hash<%s, %s, %s%s>", tau ? "true" : "false",
-           dense ? "true" : "false", c->naive ? "true" : "false",
-           (c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive) ? ", true" : "");
+  snprintf(c->launch_name[KID_HASH], sizeof c->launch_name[0], "gpc::k_hash<%s, %s, %s, %s, %d>", tau ? "true" : "false",
+           dense ? "true" : "false", c->naive ? "true" : "false", gbits ? "true" : "false", ty);
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
                      d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + (NAIVE ? 1 : 0), st, tpw)
-  // the gradient image is k_preprocess's bit image: the batched SSE pipelines (run_preprocess(..., gradbits))
-  const bool gbits = c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive;
   if (gbits) {
-#define LAUNCH_HASH_BITS(TAU)                                                                                  \
-  hipLaunchKernelGGL((gpc::k_hash<TAU, false, false, true>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p, st, tpw)
-    if (tau) LAUNCH_HASH_BITS(true); else LAUNCH_HASH_BITS(false);
+#define LAUNCH_HASH_BITS(TAU, TY, FD)                                                                                      \
+  hipLaunchKernelGGL((gpc::k_hash<TAU, false, false, true, TY>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
+                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + FD, st, tpw)
+    if (ty == HT_Y_TALL) {
+      if (tau) LAUNCH_HASH_BITS(true, HT_Y_TALL, 2); else LAUNCH_HASH_BITS(false, HT_Y_TALL, 2);
+    } else {
+      if (tau) LAUNCH_HASH_BITS(true, HT_Y, 0); else LAUNCH_HASH_BITS(false, HT_Y, 0);
+    }
 #undef LAUNCH_HASH_BITS
   } else if (c->naive) {
     if (tau && dense) LAUNCH_HASH(true, true, true);
@@ -1458,6 +1472,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (const char* e = getenv("GPC_HIP_UPLOAD")) c->upload_mode = atoi(e);
   c->no_grad_bits = getenv("GPC_HIP_NO_GRAD_BITS") != nullptr;
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
+  if (const char* e = getenv("GPC_HIP_HASH_TALL")) c->hash_tall = atoi(e) ? 1 : 0;
   c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
     const int v = atoi(e);
@@ -1636,9 +1651,10 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
       memcmp(fm->tau, c->forest_src.tau, sizeof(int32_t) * (size_t)fm->num_tests) == 0)
     return GPC_OK;
   const int W = fm->width;
-  GpcForestDev f, fn;
+  GpcForestDev f, fn, ft;  // SSE order; reversed for the Naive arithmetic; SSE order with the tall tile's LDS offsets
   memset(&f, 0, sizeof f);
   memset(&fn, 0, sizeof fn);
+  memset(&ft, 0, sizeof ft);
   for (int t = 0; t < fm->num_tests; ++t) {
     int d[4];
     for (int q = 0; q < 2; ++q) {
@@ -1651,14 +1667,18 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
       d[2 * q + 1] = dy;
     }
     // the hash kernel keeps 4 byte-shifted copies of the window: tap (dx,dy) is an aligned dword of copy dx&3
-    int offs[2];
+    int offs[2], offt[2];
     for (int q = 0; q < 2; ++q) {
       const int dx = d[2 * q], dy = d[2 * q + 1], sft = dx & 3;
       offs[q] = (sft * HT_COPY + dy * HT_STRIDE + (dx - sft)) / 4;
+      offt[q] = (sft * ((HT_Y_TALL + 2 * GPC_R) * HT_STRIDE) + dy * HT_STRIDE + (dx - sft)) / 4;
     }
     f.off[t] = (offs[0] & 0xFFFF) | (offs[1] << 16);
     f.boff[2 * t] = offs[0] * 4;
     f.boff[2 * t + 1] = offs[1] * 4;
+    ft.off[t] = (offt[0] & 0xFFFF) | (offt[1] << 16);   // (the byte offsets are what the kernels read)
+    ft.boff[2 * t] = offt[0] * 4;
+    ft.boff[2 * t + 1] = offt[1] * 4;
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
     f.tau8[t >> 2] |= (int32_t)((uint32_t)(fm->tau[t] & 0xFF) << ((t & 3) * 8));
     // gpcFilterNaive shifts the code left per test: test t ends on bit T-1-t (filter.hpp:245-249)
@@ -1668,14 +1688,16 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
     fn.boff[2 * u + 1] = f.boff[2 * t + 1];
     fn.tau[u] = fm->tau[t];              // gpcFilterTauNaive uses the int as is (:276)
   }
-  f.num_tests = fn.num_tests = fm->num_tests;
-  f.type = fn.type = fm->type ? 1 : 0;
+  memcpy(ft.tau, f.tau, sizeof f.tau);
+  memcpy(ft.tau8, f.tau8, sizeof f.tau8);
+  f.num_tests = fn.num_tests = ft.num_tests = fm->num_tests;
+  f.type = fn.type = ft.type = fm->type ? 1 : 0;
   c->forest = f;
   c->forest_naive = fn;
   HIPCHK(c, hipSetDevice(c->device));
-  CHK(ensure(c, c->forest_dev, 2 * sizeof(GpcForestDev)));
+  CHK(ensure(c, c->forest_dev, 3 * sizeof(GpcForestDev)));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // a launch in flight may still read the previous tests
-  const GpcForestDev both[2] = {f, fn};
+  const GpcForestDev both[3] = {f, fn, ft};
   HIPCHK(c, hipMemcpy(c->forest_dev.p, both, sizeof both, hipMemcpyHostToDevice));
   c->forest_w = fm->width;
   c->forest_h = fm->height;

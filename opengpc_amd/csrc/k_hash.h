@@ -201,7 +201,9 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
             ge = swar_ge(av, uaddsat_x4(bv, (uint32_t)min(-tau, 255) * 0x01000100u));
           }
         } else {
-          if (TAU) bv = subs_epi8x4(bv, (uint32_t)(tau & 0xFF) * 0x01000100u);
+          // tau is wave-uniform (a scalar load) and the loop is unrolled: a test whose tau is 0 -- _mm_subs_epi8(b, 0) = b,
+          // 7 of the 30 tests of defaultTauForest.txt -- skips the 5 operations of the saturating subtract behind a scalar branch
+          if (TAU && tau != 0) bv = subs_epi8x4(bv, (uint32_t)(tau & 0xFF) * 0x01000100u);
           ge = swar_ge(av, bv);
         }
         plane[r] = __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
@@ -234,15 +236,20 @@ __device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & SW_
 #endif
 // GBITS: `grad` is k_preprocess<..., BITS>'s bit image (one bit per pixel); a lane fetches the 16 bits of its 16-pixel group:
 // "any gradient in the group" is that word != 0 (where the byte image needs two DPP permutes), its own nibble the candidates.
-template <bool TAU, bool DENSE, bool NAIVE, bool GBITS = false>
+// TY: rows of a tile (HT_Y = 32; 40 for launches that fit ONE round of resident workgroups with the taller tile and two
+// with the lower: a single 1920x1080 pair is 528 tiles of 32 rows for 512 slots, 432 of 40 rows).  The taps' LDS offsets
+// depend on it (a shifted copy of the window is (TY + 26) rows): the host keeps one GpcForestDev per height.
+template <bool TAU, bool DENSE, bool NAIVE, bool GBITS = false, int TY = HT_Y>
 __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __restrict__ smooth,
                                               const uint8_t* __restrict__ grad,
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
                                               const GpcForestDev* __restrict__ fp, int32_t* __restrict__ img_stats,
                                               int tpw) {
-  constexpr int RPW = HT_Y / (HT_THREADS / 64);
-  __shared__ __attribute__((aligned(16))) uint8_t tile[4 * HT_COPY];
+  static_assert(TY % (HT_THREADS / 64) == 0, "a wave owns TY / 8 rows of the tile");
+  constexpr int RPW = TY / (HT_THREADS / 64);
+  constexpr int T_ROWS = TY + 2 * GPC_R, T_COPY = T_ROWS * HT_STRIDE;  // window rows; bytes of one (shifted) copy of the window
+  __shared__ __attribute__((aligned(16))) uint8_t tile[4 * T_COPY];
   __shared__ int s_cnt, s_last, s_or;
 
   // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (each with its own L2) in launch
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   // latency hides behind ~7 us of VALU/LDS work; it is written to LDS (as 4 byte-shifted copies)
   // once the current tile is done.
   constexpr int QPR = HT_STRIDE / 16;                          // 16-byte chunks per window row
-  constexpr int NCHUNK = HT_ROWS * QPR;
+  constexpr int NCHUNK = T_ROWS * QPR;
   constexpr int CPT = (NCHUNK + HT_THREADS - 1) / HT_THREADS;  // chunks per thread
   // chunk -> (window row, chunk in row), byte offset inside a copy: the same for every tile
   int crow[CPT], cdst[CPT];
@@ -351,16 +358,16 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
           w.y = __builtin_amdgcn_alignbyte(v.z, v.y, sft);
           w.z = __builtin_amdgcn_alignbyte(v.w, v.z, sft);
           w.w = __builtin_amdgcn_alignbyte(pn[i], v.w, sft);
-          *reinterpret_cast<uint4*>(dst + sft * HT_COPY) = w;
+          *reinterpret_cast<uint4*>(dst + sft * T_COPY) = w;
         }
       }
     }
   };
 
   const int tile0 = by * tpw;
-  const int ntiles = (H - 2 * GPC_R + HT_Y - 1) / HT_Y;
+  const int ntiles = (H - 2 * GPC_R + TY - 1) / TY;
   HT_STAMP_INIT();
-  fetch(GPC_R + tile0 * HT_Y);
+  fetch(GPC_R + tile0 * TY);
   int cnt = 0, last = -1;
   uint32_t cor = 0u;  // OR of the codes computed here (candidates or not: a superset costs the join nothing)
   const int T = fp->num_tests;
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   const uint32_t m8 = (x0 & 4) ? 0x01010101u : 0x01010100u;
 #pragma unroll 1
   for (int tt = 0; tt < tpw && tile0 + tt < ntiles; ++tt) {
-  const int ty0 = GPC_R + (tile0 + tt) * HT_Y;
+  const int ty0 = GPC_R + (tile0 + tt) * TY;
   if (tt) __syncthreads();  // every wave has finished reading the previous window
   HT_STAMP(0);   // wait for the other waves' tests
   stage();
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   for (int r = 0; r < RPW; ++r) gq[r] = pg[r];
   __syncthreads();
   HT_STAMP(1);   // window arrives (vmcnt), shifted copies written, barrier
-  if (tt + 1 < tpw && tile0 + tt + 1 < ntiles) fetch(ty0 + HT_Y);
+  if (tt + 1 < tpw && tile0 + tt + 1 < ntiles) fetch(ty0 + TY);
   HT_STAMP(2);   // next window's loads issued
 
   const int yw = ty0 + wave * RPW;  // first row of this wave (>= 13)
