@@ -40,8 +40,10 @@ def main():
     rows = H - 26
     M = (supports or 0.0) * B
     fused = not any("k_gather_rows" in k for k in stats)
-    must = {"k_preprocess": 6.0 * W * H * B, "k_hash": 12.0 * W * H * B,
+    g = 0.125   # the gradient image between k_preprocess and k_hash is one bit per pixel in the batched pipelines
+    must = {"k_preprocess": 2.0 * (2.0 + g) * W * H * B, "k_hash": 2.0 * (5.0 + g) * W * H * B,
             "k_row_join": 8.0 * W * rows * B + (12.0 if fused else 4.0) * M, "k_gather_rows": 16.0 * M}
+    must["k_row_join_fused"] = must["k_row_join"]
     out = {"_comment": "rocprofv3 --kernel-trace --stats averages and --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of "
                        "tools/prof_step.py %s; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction); "
                        "must_move = bytes the kernel has to read + write given its input / output formats (DESIGN.md 3)"

@@ -31,7 +31,7 @@ def main():
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     traffic["_comment"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes "
                            "(gfx950: FETCH_SIZE reports half of coalesced streaming reads); keys kernel@WxHxpairs")
-    alias = {"k_row_join": "k_row_join", "k_row_bucket": "k_row_join"}
+    alias = {"k_row_join": "k_row_join", "k_row_bucket": "k_row_join", "k_row_join_fused": "k_row_join"}
     for k, d in summ.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             base = k.replace("gpc::", "").split("<")[0]

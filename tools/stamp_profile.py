@@ -11,8 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "gpurun_out", "libgpc_hip_stamps.so")
 PHASES = ["loads+init", "insert left", "lookups+adds", "decide", "rank count", "rank scan+scatter", "rank walk+store"]
-FUSED_PHASES = ["loads+init (+ pending row asks)", "insert left", "lookups+adds", "decide (+count)",
-                "rank count (+ pending row's place)", "pending row's records out + scan + scatter", "rank walk"]
+# k_row_join_fused (round 4): stamps at its barriers B0, B1, B2, B3, before the scan, B6, end of the row
+FUSED_PHASES = ["codes arrive, keys, clears (-> B0)", "insert left + flag clear + ticket draw (-> B1)", "lookups + marks (-> B2)",
+                "pending row's place, decide, rank count (-> B3)", "count out, bucket counts read, pending row's records out",
+                "scan + starts + shared buckets' codes (-> B6)", "walk, ranked words, next row's loads asked for"]
 HASH_PHASES = ["wait for other waves", "window arrives + staged + barrier", "next window's loads issued", "candidate flags",
                "tests + transposes", "code stores issued"]
 
@@ -58,9 +60,10 @@ def main():
     names = FUSED_PHASES if fused else PHASES
     tot = sum(buf[i] for i in range(len(names)))
     print("k_row_join (%s) phase shares (s_memtime ticks summed over the sampled workgroups' rows):" % ("fused output" if fused else "two launches"))
+    nrows_sampled = 4 * B * (H - 26) / 64.0   # one workgroup in 64 reports, 4 launches since the last read
     for i, name in enumerate(names):
-        print("  %-24s %6.1f %%" % (name, 100.0 * buf[i] / tot))
-    print("  total %.0f ticks" % tot)
+        print("  %-62s %6.1f %%  %7.0f cycles per row" % (name, 100.0 * buf[i] / tot, buf[i] / nrows_sampled))
+    print("  total %.0f ticks = %.0f cycles per row of a sampled workgroup (%s workgroups)" % (tot, tot / nrows_sampled, os.environ.get("GPC_HIP_FUSE_WGS", "all resident")))
     HJ = ["bin bounds (scalar loads)", "records arrive", "buckets + counts", "scan", "placed", "10-cap", "ranks",
           "list order + links", "walk + scan", "output"]
     hs = g.Settings(5, 128, 1, True, True, 1)
