@@ -81,8 +81,8 @@ class HostChild:
         while self._line() != "ready":
             pass
 
-    def call(self):
-        self.p.stdin.write("go\n")
+    def call(self, cmd="go"):
+        self.p.stdin.write(cmd + "\n")
         self.p.stdin.flush()
         return float(self._line())
 
@@ -346,6 +346,7 @@ def main():
     #      CHILD process without torch -- the C++ caller's situation -- and this process only carries the barriers and
     #      tells the child when to go.  At one rank the same call is also timed inside this process, for the record.
     host_reps, host_times, host_ok, host_threads, child_rec = 15, [], True, 0, None
+    packed_reps, packed_times = 9, []
     inproc_times = []
     if not args.no_extras or args.host_path:
         child = HostChild(B, W, H, args.forest, dev_index)
@@ -357,6 +358,9 @@ def main():
             res_t = []
             gdist.timed_calls(child_call, host_reps)   # barrier before each repetition; the child times its own call
             host_times = res_t
+            # and the packed variant of the same call (gpc_hip_match_batch_packed: the records stay 4 bytes each in host
+            # memory -- what a node of 8 ranks has the memory bandwidth for)
+            gdist.timed_calls(lambda: packed_times.append(child.call("gop")), packed_reps)
             child_rec = child.finish()
         finally:
             child.kill()
@@ -367,6 +371,7 @@ def main():
         for j in sorted(set((0, B // 2, B - 1))):   # the device path's 12-byte records of three pairs, byte for byte
             host_ok = host_ok and zlib.crc32(d_out[j, : int(counts[j])].cpu().numpy().tobytes()) == crc[str(j)]
         host_threads = int(child_rec.get("host", {}).get("expand_threads", 0))
+        host_ok = host_ok and bool(child_rec.get("packed", {}).get("identical_to_expanded", False))
         if world == 1:
             capi_cap = 300000
             Lp, Rp = ctx.pinned_empty(Lh.shape, np.uint8), ctx.pinned_empty(Rh.shape, np.uint8)
@@ -387,12 +392,22 @@ def main():
     # O(100 B) per rank over xGMI: timing / counters only, never pixel data
     row = [float(B), float(ncand.sum()), float(counts.sum()), 1.0 if verified in (True, None) else 0.0,
            float(n_verified), 1.0 if host_ok else 0.0, float(host_threads)] + [float(t) for t in host_times] + \
-          [float(t) for t in windows]
+          [float(t) for t in packed_times] + [float(t) for t in windows]
     allr = gdist.gather_stats(row, device=stat_dev).numpy()
     if float(allr[:, 3].min()) < 1.0:
         raise SystemExit("bench.py: GPU supports differ from the oracle on some rank -- refusing to report a number")
-    nh = len(host_times)
-    win = np.sort(allr[:, 7 + nh:].max(axis=0))     # per window: the slowest rank
+    nh, npk = len(host_times), len(packed_times)
+    win = np.sort(allr[:, 7 + nh + npk:].max(axis=0))     # per window: the slowest rank
+    host_packed = None
+    if npk:
+        hp = np.sort(allr[:, 7 + nh:7 + nh + npk].max(axis=0))
+        tpk = float(hp[len(hp) // 2])
+        host_packed = {"ms_per_call": round(tpk * 1e3, 3), "value": round(2.0 * W * H * float(allr[:, 0].sum()) / tpk / 1e6, 1),
+                       "unit": "Mpix/s", "pairs_per_call_per_rank": B, "ranks": int(world),
+                       "ms_per_call_min": round(float(hp[0]) * 1e3, 3), "ms_per_call_max": round(float(hp[-1]) * 1e3, 3),
+                       "note": "gpc_hip_match_batch_packed on every rank at the same moment: host images -> packed records in host "
+                               "memory (4 bytes per support + row counts: what crosses the link), the same pipeline without the "
+                               "expansion to 12-byte ndb::Support records; median of %d repetitions, same children" % npk}
     host_all = None
     if nh:
         hs = np.sort(allr[:, 7:7 + nh].max(axis=0))  # per repetition: the slowest rank
@@ -597,6 +612,7 @@ def main():
             "single_pair": single,
             "single_pair_host_to_host": single_h2h,
             "host_to_host_all_ranks": host_all,
+            "host_to_host_packed_all_ranks": host_packed,
             "two_stream_pipeline": two,
         }
         if cpu:

@@ -202,6 +202,16 @@ int gpc_hip_match_batch_device_packed(gpc_hip_ctx* ctx, const uint8_t* d_rawL, c
                                       int width, int height, int npairs, const gpc_settings* settings,
                                       uint32_t* d_packed, int cap_per_pair, int32_t* d_rows,
                                       int32_t* d_counts, int32_t* d_ncand);
+/* The same from / to HOST memory, synchronous (the chunk pipeline of gpc_hip_match_batch without its last stage): the
+ * records stay as they crossed the link -- packed[npairs][cap_per_pair] words, rows[npairs][height] per-row counts (rows
+ * outside 13 .. height-14 hold 0), counts[npairs] the true totals (GPC_E_CAPACITY when one exceeds cap_per_pair; the pair's
+ * first cap_per_pair records are delivered).  For callers that consume supports row by row, or that expand them later /
+ * elsewhere with gpc_hip_expand_packed: a batch of 256 pairs of 1024x436 leaves 209 MB in host memory where the
+ * ndb::Support arrays of gpc_hip_match_batch are 625 MB -- with one process per GPU on an 8-GPU node those 12-byte records
+ * are what the host's memory bandwidth runs out on.  Epipolar sort-matcher only (GPC_E_UNSUPPORTED otherwise). */
+int gpc_hip_match_batch_packed(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR, int width, int height,
+                               int npairs, const gpc_settings* settings, uint32_t* packed, int cap_per_pair,
+                               int32_t* rows, int32_t* counts, int32_t* ncand);
 /* Host only: the first n supports of one pair from its packed words and row counts. */
 int gpc_hip_expand_packed(const uint32_t* packed, const int32_t* rows, int height, int n, gpc_support* out);
 

@@ -73,7 +73,7 @@ SYMBOLS = [
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
-    "gpc_hip_match_batch_device_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
+    "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
     "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
@@ -126,6 +126,8 @@ def load():
     L.gpc_hip_match_batch_device_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                     C.POINTER(Settings), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                     C.c_void_p]
+    L.gpc_hip_match_batch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gpc_hip_expand_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.gpc_hip_host_threads.argtypes = [C.c_void_p]
     L.gpc_hip_host_numa_node.argtypes = [C.c_void_p]
@@ -342,6 +344,23 @@ class Context:
                                         _ptr(counts), _ptr(ncand))
         self._ck(st, allow=(E_CAPACITY,))
         return out, counts, ncand, st
+
+    def match_batch_packed(self, rawL, rawR, settings, cap, packed=None, rows=None):
+        """Host images -> PACKED results in host memory (gpc_hip_match_batch_packed): words xL | xR << 16 [P][cap], per-row
+        counts [P][H], true counts [P], candidate counts [P][2]; expand_packed() makes a pair's ndb::Support records."""
+        rawL = np.ascontiguousarray(rawL, np.uint8)
+        rawR = np.ascontiguousarray(rawR, np.uint8)
+        P, H, W = rawL.shape
+        if packed is None:
+            packed = np.empty((P, cap), np.uint32)
+        if rows is None:
+            rows = np.empty((P, H), np.int32)
+        counts = np.empty(P, np.int32)
+        ncand = np.empty((P, 2), np.int32)
+        st = self.L.gpc_hip_match_batch_packed(self.h, _ptr(rawL), _ptr(rawR), W, H, P, C.byref(settings), _ptr(packed), cap,
+                                               _ptr(rows), _ptr(counts), _ptr(ncand))
+        self._ck(st, allow=(E_CAPACITY,))
+        return packed, rows, counts, ncand, st
 
     # ---- device-resident batch (pointers are integers, e.g. torch.Tensor.data_ptr())
     def match_batch_device(self, d_rawL, d_rawR, width, height, npairs, settings, d_out, cap_per_pair,

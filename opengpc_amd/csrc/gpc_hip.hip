@@ -1979,8 +1979,14 @@ int gpc_hip_expand_packed(const uint32_t* packed, const int32_t* rows, int H, in
 // expand them into the caller's ndb::Support arrays while the next chunks are uploaded, matched and downloaded.
 // Per chunk k:  upload (s_in) -> kernels (stream) -> counts (s_cnt) | download of k-1 (s_out) | expansion of k-2 (pool).
 // Device results rotate through 3 slots, the page-locked landing area through 4.
+// ph != null: the results are LEFT packed in the caller's arrays (gpc_hip_match_batch_packed) instead of being expanded into `out`
+struct PackedHost {
+  uint32_t* packed;  // [npairs][cap] words xL | xR << 16
+  int32_t* rows;     // [npairs][H] supports per row
+};
 static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
-                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand);
+                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand,
+                              const PackedHost* ph = nullptr);
 
 // The device's address of page-locked host memory the GPU can write (hipHostMalloc / gpc_hip_host_alloc), or null.
 static void* device_view_of_host(const void* p) {
@@ -2063,15 +2069,19 @@ int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR
 }
 
 static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
-                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
-  if (!c || !rawL || !rawR || !out || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
+                              const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand,
+                              const PackedHost* ph) {
+  if (!c || !rawL || !rawR || (!out && !ph) || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
+  if (ph && (!ph->packed || !ph->rows)) return GPC_E_INVALID;
   CHK(check_settings(s));
-  if (!s->epipolar_mode || s->use_hashtable)
+  if (!s->epipolar_mode || s->use_hashtable) {
+    if (ph) return GPC_E_UNSUPPORTED;  // rows are the unit of the packed format: the epipolar sort-matcher's
     return match_batch_unpacked(c, rawL, rawR, W, H, npairs, s, out, cap, counts, ncand);
+  }
   CHK(check_dims(W, H));
   CHK(forest_matches(c, W, H));
   HIPCHK(c, hipSetDevice(c->device));
-  if (npairs <= c->direct_max && (uint64_t)cap * sizeof(gpc_support) < (1ull << 32))
+  if (!ph && npairs <= c->direct_max && (uint64_t)cap * sizeof(gpc_support) < (1ull << 32))
     if (void* dv = device_view_of_host(out))
       return match_batch_direct(c, rawL, rawR, W, H, npairs, s, (gpc_support*)dv, cap, counts, ncand);
   const size_t n = (size_t)W * H;
@@ -2188,6 +2198,25 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
       const int cnt = counts[p0 + i];
       const long limit = cnt < cap ? cnt : cap;
       long first = 0;
+      if (ph) {  // the pair's words and row counts as they came over the link: two plain copies instead of the expansion
+        ExpandJob j = {};
+        j.slot = k & 3;
+        int32_t* rdst = ph->rows + (size_t)(p0 + i) * H;   // rows 13 .. H-14 are the device's; the margins hold no support
+        memset(rdst, 0, sizeof(int32_t) * GPC_R);
+        memset(rdst + H - GPC_R, 0, sizeof(int32_t) * GPC_R);
+        j.copy_src = rows + GPC_R;
+        j.copy_dst = rdst + GPC_R;
+        j.copy_bytes = sizeof(int32_t) * (size_t)(H - 2 * GPC_R);
+        c->pool.push(j);
+        if (limit > 0) {
+          j.copy_src = recs;
+          j.copy_dst = ph->packed + (size_t)(p0 + i) * cap;
+          j.copy_bytes = rec * (size_t)limit;
+          c->pool.push(j);
+        }
+        recs += rec * (size_t)limit;
+        continue;
+      }
       for (int q = 0; q < parts; ++q) {
         const int y0 = GPC_R + (int)((long)(H - 2 * GPC_R) * q / parts), y1 = GPC_R + (int)((long)(H - 2 * GPC_R) * (q + 1) / parts);
         if (first < limit && y1 > y0)
@@ -2252,6 +2281,22 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
   HIPCHK(c, hipStreamSynchronize(c->stream));
   CHK(check_join_err(c));
   return status;
+}
+
+int gpc_hip_match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
+                               const gpc_settings* s, uint32_t* packed, int cap, int32_t* rows, int32_t* counts, int32_t* ncand) {
+  const PackedHost ph = {packed, rows};
+  const int st = match_batch_packed(c, rawL, rawR, W, H, npairs, s, nullptr, cap, counts, ncand, &ph);
+  if (c && st != GPC_OK && st != GPC_E_CAPACITY && st != GPC_E_INVALID && st != GPC_E_UNSUPPORTED) {
+    c->pool.wait_all();   // (as in gpc_hip_match_batch: nothing of a failed call may still be in flight)
+    if (c->s_in) {
+      (void)hipStreamSynchronize(c->s_in);
+      (void)hipStreamSynchronize(c->s_out);
+      (void)hipStreamSynchronize(c->s_cnt);
+    }
+    (void)hipStreamSynchronize(c->stream);
+  }
+  return st;
 }
 
 int gpc_hip_host_threads(const gpc_hip_ctx* c) { return c ? c->pool.size() : 0; }

@@ -256,6 +256,17 @@ def test_packed_results_equal_the_12_byte_path(oracle, forest_paths):
                     for i in range(P):
                         k = min(int(cnt[i]), hcap)
                         assert np.array_equal(o[i, :k], ref[i][:k]), (W, H, hcap, pinned, i)
+                # gpc_hip_match_batch_packed: the same pipeline with the records LEFT packed in host memory
+                hp, hr, c3, n3, st = ctx.match_batch_packed(Lh, Rh, s, hcap)
+                assert np.array_equal(c3, cnt) and np.array_equal(n3, d_nc.cpu().numpy())
+                assert st == (g.capi.E_CAPACITY if (cnt > hcap).any() else 0)
+                for i in range(P):
+                    k = min(int(cnt[i]), hcap)
+                    assert np.array_equal(hr[i, 13:H - 13], rows[i, 13:H - 13]) and hr[i, :13].sum() == 0 and hr[i, H - 13:].sum() == 0
+                    assert np.array_equal(hp[i, :k], pk[i, :k]), (W, H, hcap, i)
+                    assert np.array_equal(g.capi.expand_packed(hp[i], hr[i], k), ref[i][:k])
+            with pytest.raises(g.GpcError):   # rows are the unit of the packed format: the other matcher modes refuse it
+                ctx.match_batch_packed(Lh, Rh, g.Settings(5, disp, 0, False, False, 1), cap)
     finally:
         ctx.close()
 

@@ -69,9 +69,14 @@ def serve(B, W, H, forest, dev_index, warm=5):
     st, counts, o = 0, None, None
     for _ in range(warm):
         o, counts, ncand, st = ctx.match_batch(Lp, Rp, s, cap, out=out)
+    # the same call with the records LEFT packed (gpc_hip_match_batch_packed): 4 bytes per support + row counts
+    pk, prow = ctx.pinned_empty((B, cap), np.uint32), ctx.pinned_empty((B, H), np.int32)
+    pst, pcounts = 0, None
+    for _ in range(2):
+        pk, prow, pcounts, pncand, pst = ctx.match_batch_packed(Lp, Rp, s, cap, packed=pk, rows=prow)
     sys.stdout.write("ready\n")
     sys.stdout.flush()
-    tt = []
+    tt, tp = [], []
     for line in sys.stdin:
         cmd = line.strip()
         if cmd == "go":
@@ -81,6 +86,13 @@ def serve(B, W, H, forest, dev_index, warm=5):
             tt.append(dt)
             sys.stdout.write("%.9f\n" % dt)
             sys.stdout.flush()
+        elif cmd == "gop":
+            t0 = time.perf_counter()
+            pk, prow, pcounts, pncand, pst = ctx.match_batch_packed(Lp, Rp, s, cap, packed=pk, rows=prow)
+            dt = time.perf_counter() - t0
+            tp.append(dt)
+            sys.stdout.write("%.9f\n" % dt)
+            sys.stdout.flush()
         elif cmd == "done":
             break
     rec = {"status": int(st), "calls": len(tt), "pairs_per_call": B, "host_buffers": "page-locked (gpc_hip_host_alloc)",
@@ -88,6 +100,12 @@ def serve(B, W, H, forest, dev_index, warm=5):
            "bytes_delivered": int(counts.sum()) * 12, "counts": [int(v) for v in counts],
            "crc32": {str(j): zlib.crc32(o[j, : int(counts[j])].tobytes()) for j in sorted(set((0, B // 2, B - 1)))},
            "host": host_info(ctx)}
+    # the packed call against the expanded one: same counts, and three pairs expanded on the host record for record
+    ok = bool(pst == 0 and np.array_equal(pcounts, counts))
+    for j in sorted(set((0, B // 2, B - 1))):
+        ok = ok and np.array_equal(g.capi.expand_packed(pk[j], prow[j], int(counts[j])), o[j, : int(counts[j])])
+    rec["packed"] = {"status": int(pst), "calls": len(tp), "identical_to_expanded": ok,
+                     "bytes_delivered": int(counts.sum()) * 4 + B * H * 4}
     if rank == 0 and not os.environ.get("GPC_BENCH_NO_SINGLE"):
         rec["single_pair_host_to_host"] = single_pair(ctx, W, H, s)
     sys.stdout.write(json.dumps(rec) + "\n")
