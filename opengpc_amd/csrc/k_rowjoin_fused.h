@@ -240,6 +240,34 @@ __device__ __forceinline__ uint32_t rjf_walk(uint32_t keys_lds, uint32_t s0, uin
   return rank;
 }
 
+// rj_insert_chain with its end state handed back: cur = the key the lane carried last, o = what its last probe returned.
+// o == cur (and cur != 0) says the carried key met a copy of itself: that key occurs twice among the left records.
+__device__ __forceinline__ void rjf_insert_chain(uint32_t keys_lds, uint32_t& cur, uint32_t& o, uint32_t h, uint32_t smask) {
+  uint32_t addr;
+  unsigned long long sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[cur]\n\t"       // lanes without a record never probe on
+      "v_cmpx_ne_u32_e32 vcc, 0, %[o]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_min_u32_e32 %[cur], %[o], %[cur]\n\t"
+      "v_add_u32_e32 %[h], 1, %[h]\n\t"
+      "v_and_b32_e32 %[h], %[smask], %[h]\n\t"
+      "v_lshl_add_u32 %[addr], %[h], 2, %[base]\n\t"
+      "ds_max_rtn_u32 %[o], %[addr], %[cur]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[o]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
+      "s_cbranch_execnz 1b\n"
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [cur] "+v"(cur), [o] "+v"(o), [h] "+v"(h), [addr] "=&v"(addr), [sv] "=&s"(sv)
+      : [smask] "s"(smask), [base] "s"(keys_lds)
+      : "vcc", "memory");
+}
+
 // Home slot of key k: its hash -- or, for a pixel slot without a record (k == 0), a slot of the lane's own (idx): the
 // no-op atomics and reads of such slots then never share an address.  Without a select the compiler turns into a branch
 // (six scalar instructions of EXEC bookkeeping per slot): codes below 2^31 (every arithmetic but 32-test SSE=OFF) make
@@ -269,7 +297,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   constexpr uint32_t smask = (uint32_t)S - 1u;
   constexpr int hshift = 32 - rjf_log2(S);
   // flags of a table slot: halfwords, two slots per word, x of a right record in the low 12 bits
-  constexpr uint32_t F_LSEEN = 0x1000u, F_LDUP = 0x2000u, F_RSEEN = 0x4000u, F_RDUP = 0x8000u, F_XMASK = 0x0FFFu;
+  constexpr uint32_t F_LDUP = 0x2000u, F_RSEEN = 0x4000u, F_RDUP = 0x8000u, F_XMASK = 0x0FFFu;  // (0x1000: unused since round 4 -- left records need no SEEN flag)
   extern __shared__ __attribute__((aligned(16))) uint32_t rjf_lds[];
   __shared__ uint32_t s_max_key;
   __shared__ int s_tail_cnt;
@@ -424,6 +452,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     // ---- 1. build the ordered table from the left codes; the flag words are cleared meanwhile (the inserts touch keys only)
     uint32_t h0l[SPT];
+    uint32_t ldup = 0u;          // bit j: the code of left pixel slot j occurs at least twice on the left
+    uint32_t carried[SPT];       // a displaced key this lane saw meet its copy (0: none -- the rule)
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) carried[j] = 0u;
     {
       uint32_t old[SPT];
 #pragma unroll
@@ -442,9 +474,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int i = 0; i < (NZF + NT - 1) / NT; ++i)
           if (NZF % NT == 0 || tid + i * NT < NZF) zf[tid + i * NT] = make_uint4(z0, z0, z0, z0);
       }
-      {
+      // A code that occurs twice among the left records is noticed HERE, by the lane whose carried key meets a copy of
+      // itself (the probe returns the key it carries): total records - distinct keys such events, at least one per repeated
+      // code, each seen by one lane.  Nearly always that lane carries its OWN key (it never displaced anything): it sets
+      // the left-duplicate flag on its own slot after the lookup, and no left record needs a returning mark to find out
+      // (round 3: four returning ds_or per wave and row).  A lane that carried a DISPLACED key into its copy (two copies
+      // of a code and a larger code racing over the same slots) remembers that key and marks its slot after the barrier.
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) rj_insert_chain(keys_lds, kl[j], old[j], h0l[j], smask);
+      for (int j = 0; j < SPT; ++j) {
+        uint32_t cur = kl[j], o = old[j];
+        rjf_insert_chain(keys_lds, cur, o, h0l[j], smask);
+        const bool met = kl[j] && o == cur;
+        if (met && cur == kl[j]) ldup |= 1u << j;
+        else if (met) carried[j] = cur;
       }
     }
     if (tail_row) {  // the largest right key of this row (block-uniform branch)
@@ -502,13 +544,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
       }
 #pragma unroll
-      for (int j = 0; j < SPT; ++j) {
-        mv[j] = (kl[j] ? F_LSEEN : 0u) << ((hl[j] & 1u) << 4);
-        seen[j] = atomicOr(&t_w[hl[j] >> 1], mv[j]);
-      }
+      for (int j = 0; j < SPT; ++j)  // a repeated left code: the flag goes onto the code's slot (every copy of it reads that slot)
+        if ((ldup >> j) & 1u) atomicOr(&t_w[hl[j] >> 1], F_LDUP << ((hl[j] & 1u) << 4));
+      {  // the rare displaced key that met its copy: find its slot like any lookup and flag it (wave-uniform skip otherwise)
+        uint32_t anyc = 0u;
 #pragma unroll
-      for (int j = 0; j < SPT; ++j)  // a second left record of this code: it found the bit it was about to set (mv = 0 without a record)
-        if (seen[j] & mv[j]) atomicOr(&t_w[hl[j] >> 1], mv[j] << 1);  // F_LDUP = F_LSEEN << 1
+        for (int j = 0; j < SPT; ++j) anyc |= carried[j];
+        if (__ballot(anyc != 0u)) {
+#pragma unroll
+          for (int j = 0; j < SPT; ++j) {
+            const uint32_t hc0 = rj_hash(carried[j], hshift);
+            uint32_t kk = carried[j] ? t_key[hc0] : 0u;
+            const uint32_t hc = rj_find_chain(keys_lds, carried[j], kk, hc0, smask);
+            if (carried[j]) atomicOr(&t_w[hc >> 1], F_LDUP << ((hc & 1u) << 4));
+          }
+        }
+      }
       uint32_t hr[SPT];
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
