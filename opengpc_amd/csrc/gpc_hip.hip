@@ -671,7 +671,7 @@ JoinPlan plan_join(const gpc_hip_ctx* c, int W) {
 int check_join_err(gpc_hip_ctx* c) {
 #ifdef RJ_DBG_COUNT
   if (c->h_err && c->h_err[1]) {
-    fprintf(stderr, "[RJ_DBG_COUNT] look-backs %d, first window not ready %d, further polls %d\n", c->h_err[1], c->h_err[2], c->h_err[3]);
+    fprintf(stderr, "[RJ_DBG_COUNT] look-backs %d, windows with a row that had not published %d, displaced keys that met their copy %d\n", c->h_err[1], c->h_err[2], c->h_err[3]);
     c->h_err[1] = c->h_err[2] = c->h_err[3] = 0;
   }
 #endif

@@ -557,6 +557,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             uint32_t kk = carried[j] ? t_key[hc0] : 0u;
             const uint32_t hc = rj_find_chain(keys_lds, carried[j], kk, hc0, smask);
             if (carried[j]) atomicOr(&t_w[hc >> 1], F_LDUP << ((hc & 1u) << 4));
+#ifdef RJ_DBG_COUNT
+            if (carried[j]) atomicAdd(rjf_args()->err + 3, 1);  // [3] displaced keys that met their copy
+#endif
           }
         }
       }
