@@ -208,7 +208,7 @@ struct gpc_hip_ctx {
   int fuse_always = 0;        // GPC_HIP_FUSE_ALWAYS: the fused join wherever it is possible, however small the launch (tests, A/B checks)
   int fuse_wgs = 0;           // GPC_HIP_FUSE_WGS: workgroups of the persistent join (tuning; default = what the device holds)
   int fuse_min_pairs = 1;     // GPC_HIP_FUSE_MIN_PAIRS: smaller batches take the two-launch path
-  int fuse_shards = 16;       // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (tuning)
+  int fuse_shards = 0;        // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (0: join_shards() chooses)
   int num_cus = 0;
   std::map<std::pair<const void*, size_t>, int> wgs_per_cu;  // occupancy of the persistent instantiations launched so far, per LDS size
   std::map<const void*, int> dyn_lds;     // largest dynamic-LDS size a kernel has been allowed so far (hipFuncSetAttribute once, not per call)
@@ -687,6 +687,31 @@ int check_join_err(gpc_hip_ctx* c) {
   return GPC_OK;
 }
 
+// Ticket counters (shards of pairs) of a fused launch.  Workgroup b serves shard b % shards and lands on XCD b % 8, so
+//   * 8 | shards pins every shard -- its pairs -- to one XCD, and the XCDs finish apart: 256 pairs with 8 / 16 / 32 / 64
+//     shards 567-570 us, with 3 .. 13 shards 550-554 us (15 / 17 / 21 / 31: 561 / 562 / 565 / 573; 2 shards 653 and one
+//     shard 1246: same-address atomics on the counter);
+//   * a shard's workgroups take only its rows, so shards of unequal size finish apart as well: 8 pairs of 1920x1080 over
+//     7 shards (one of them two pairs) 155 us against 123 over 8.
+// So: 3 .. 13 shards, not a multiple of 8, the least time the fullest shard runs alone; ties go to the count nearest 7.
+int join_shards(const gpc_hip_ctx* c, int npairs) {
+  if (c->fuse_shards > 0) return npairs < c->fuse_shards ? npairs : c->fuse_shards;
+  if (npairs <= 3) return npairs;
+  int best = 3;
+  long best_waste = -1;
+  for (int n = 3; n <= 13 && n <= npairs; ++n) {
+    if (n % 8 == 0) continue;
+    long waste = ((long)((npairs + n - 1) / n) * n - npairs) * 1000 / npairs;   // per mille of the launch the fullest shard runs alone
+    if (waste <= 15) waste = 0;                                                   // (below the boxes' run-to-run spread)
+    const bool nearer = abs(n - 7) < abs(best - 7);
+    if (best_waste < 0 || waste < best_waste || (waste == best_waste && nearer)) {
+      best = n;
+      best_waste = waste;
+    }
+  }
+  return best;
+}
+
 // State of the fused join: ticket counters + one granule per (pair, row); zeroed when (re)allocated, then kept
 // consistent by the kernel itself (the last draw resets a counter; granules carry the launch's epoch).
 int ensure_join_state(gpc_hip_ctx* c, size_t granules) {
@@ -796,7 +821,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     long nwg = c->fuse_wgs > 0 ? c->fuse_wgs : (long)per_cu * c->num_cus;                                       \
     if (nwg > (long)npairs * nrows) nwg = (long)npairs * nrows;                                                 \
     /* every shard needs a workgroup that draws its tickets (workgroup b serves shard b % nshards) */           \
-    int nsh = npairs < c->fuse_shards ? npairs : c->fuse_shards;                                                \
+    int nsh = join_shards(c, npairs);                                                                           \
     if (nsh > nwg) nsh = (int)nwg;                                                                              \
     a.nshards = nsh;                                                                                            \
     if (getenv("GPC_HIP_DEBUG")) fprintf(stderr, "[gpc_hip] k_row_join_fused<%d, %d>: %d workgroups per CU by the occupancy API, %ld workgroups, %d shards, %zu B of LDS\n", SPT, NT, per_cu, nwg, nsh, lds); \
