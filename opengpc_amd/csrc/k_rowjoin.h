@@ -25,6 +25,10 @@
 //      (DPP wave scan), and a look at the < 1 other matches sharing the bucket.
 //      The thread still holds xL and xR, so it writes the packed support straight to its place.
 //
+// This header is the ONE-ROW-PER-WORKGROUP form: small launches, rows wider than 4096 pixels, the host entry point's gap-free
+// packing (join + k_gather_rows as two launches) and, with VIRT, the partitions of the non-epipolar matcher.  Batched launches
+// take k_rowjoin_fused.h: the same join as a persistent kernel that also writes the supports.
+//
 // 32-bit codes (WIDE): the SSE=OFF arithmetic with a 32-test forest sets bit 31, and the code
 // 0xFFFFFFFF then collides with both sentinels (GPC_NOCAND in the code image, key 0 = code + 1
 // in the table).  The WIDE instantiations read the candidate byte of such pixels to tell them

@@ -23,23 +23,29 @@
 //     row put that wait on every row's critical path.  So row n asks for its predecessors' granules after row n+1's
 //     insert phase, looks at the answer after row n+1's lookup phase and writes row n's records while row n+1 ranks.
 //
-// Round 4: a kernel of its own (it was the FUSE instantiation of k_row_join), written for its instruction budget --
-// the kernel is bound by the SUM of its vector and LDS instruction issue:
-//   * ONE by-value parameter (RjfArgs), read from the kernel-argument segment with scalar loads AT THE POINT OF USE
-//     (rjf_args()): as ordinary parameters the ~40 words stayed live in SGPRs for the whole persistent loop and, at the 80
-//     SGPRs eight waves per SIMD leave a wave, 42 of them were spilled to VGPR lanes (~100 v_readlane per wave and row);
+// Round 4: a kernel of its own (it was the FUSE instantiation of k_row_join).  What binds it ("what binds
+// the fused join"): the ~11 us a row spends inside its workgroup times the eight rows a CU holds -- all 32 wave slots and all
+// 160 KB of LDS -- not instruction count, LDS throughput, HBM latency or barriers (each was varied by itself).  What changed:
+//   * ONE by-value parameter (RjfArgs).  What every wave needs on its critical path (W, H, code image, statistics, filter
+//     settings) is used by value; the rest is loaded from the kernel-argument segment (rjf_args()) by the one wave that
+//     uses it.  As ~40 ordinary parameters they stayed live in SGPRs for the whole persistent loop and, at the 80 SGPRs
+//     eight waves per SIMD leave a wave, 42 of them were spilled to VGPR lanes; now 0-11, and no scratch anywhere;
 //   * the table size is a compile-time constant (S = 2 * NT * SPT): masks, shifts and LDS offsets are immediates;
 //   * lane predicates (tid == 0, x < W, ...) are recomputed from an opaque thread index where they are used instead of
-//     being kept as 64-bit masks across the row (one v_cmp where a spilled mask costs two v_readlane);
+//     being kept as 64-bit masks across the row;
 //   * ticket -> (pair, row) by a host-made multiply-high instead of a scalar division sequence per row;
 //   * LDS regions no longer alias across phases that a barrier had to separate: the rank counters have a region of
 //     their own (cleared with the key table at the top of the row), the matched codes of shared buckets live in the flag
 //     words (dead after the decide phase, cleared during the NEXT row's insert phase), so the decide phase runs straight
 //     into the rank-count atomics and the row's last phase straight into the next row's clear: 7 barriers per row, not 9
-//     (the LDS of a 1024-pixel row is 20 384 + 56 bytes: exactly the sixteen 1280-byte granules an eighth of a CU holds);
+//     (the LDS of a 1024-pixel row is 20 384 + 48 bytes: exactly the sixteen 1280-byte granules an eighth of a CU holds);
+//   * a code that occurs twice among the LEFT records is noticed at insert time, by the lane whose carried key meets its
+//     copy: left records need no returning mark (4 LDS atomics and a dependent round trip per row less);
 //   * rank phase: a match reads its bucket's COUNT before the scan turns the counters into starts -- four matches in
 //     five are alone in their bucket and need neither a place among the bucket's codes nor the walk over them; the walk
-//     itself is a hand-written v_cmpx / s_cbranch_execnz loop like the probe loops.
+//     itself is a hand-written v_cmpx / s_cbranch_execnz loop like the probe loops;
+//   * the host deals the pairs over 3 .. 13 ticket counters, never a multiple of 8: workgroup b serves shard b % shards
+//     and runs on XCD b % 8, and a shard pinned to one XCD made the XCDs finish apart (gpc_hip.hip: join_shards).
 #pragma once
 #include <cstddef>
 
