@@ -190,11 +190,6 @@ int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* ra
 int gpc_hip_host_threads(const gpc_hip_ctx* ctx);
 /* The NUMA node of the host this context's GPU hangs off (the expansion workers are bound to its CPUs), -1 if unknown. */
 int gpc_hip_host_numa_node(const gpc_hip_ctx* ctx);
-/* 1 while the expansion workers are bound to that node's CPUs, 0 while they run wherever the process may.  A context TRIES
- * both on its first large calls (call 2 bound, call 3 unbound) and keeps the faster: bound, the workers write the page-locked
- * result arrays locally; on a host shared with other jobs the GPU's node may be the busy one (8.5 against 5.3 ms per 256 pairs
- * measured).  GPC_HIP_NUMA_BIND=1 / GPC_HIP_NO_NUMA_BIND=1 in the environment force either. */
-int gpc_hip_host_workers_bound(const gpc_hip_ctx* ctx);
 
 /* ---- packed results ------------------------------------------------------------ */
 /* Forest::rectifiedMatch (inference.hpp:375-393) in epipolar mode emits supports row by row, so a support

@@ -73,7 +73,7 @@ SYMBOLS = [
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
-    "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node", "gpc_hip_host_workers_bound",
+    "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
     "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
@@ -131,7 +131,6 @@ def load():
     L.gpc_hip_expand_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.gpc_hip_host_threads.argtypes = [C.c_void_p]
     L.gpc_hip_host_numa_node.argtypes = [C.c_void_p]
-    L.gpc_hip_host_workers_bound.argtypes = [C.c_void_p]
     L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.gpc_hip_set_kernel_timing_mask.argtypes = [C.c_void_p, C.c_uint]
     L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]

@@ -9,11 +9,8 @@
 #include <emmintrin.h>   // the host expansion of packed results has an SSE2 path (x86 hosts); scalar otherwise
 #endif
 #include <sched.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 
 #include <cctype>
-#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -94,8 +91,7 @@ class ExpandPool {
   // bind: CPUs the workers may run on (the NUMA node of the GPU: the page-locked buffers they read and write live there,
   // and workers that land on the other socket made the same call take 7.3 instead of 5.4 ms); null = wherever
   void start(int nthreads, const cpu_set_t* bind) {
-    const bool same_bind = (bind != nullptr) == have_bind_ && (!bind || CPU_EQUAL(bind, &bind_));
-    if ((int)threads_.size() == nthreads && same_bind) return;
+    if ((int)threads_.size() == nthreads) return;
     stop();
     quit_ = false;
     have_bind_ = bind != nullptr;
@@ -169,15 +165,6 @@ struct gpc_hip_ctx {
   int upload_mode = 1;            // GPC_HIP_UPLOAD: single-pair host path -- 0: hipMemcpyAsync per side, 1: one k_upload2 launch, 2: k_preprocess reads the host's pages
   int direct_max = 2;             // GPC_HIP_DIRECT_MAX: batches up to this size with a page-locked `out` are written by the
                                   // kernels straight into the caller's array (no packed records, no host expansion); 0 = never
-  // Where the expansion workers run.  Bound to the CPUs of the GPU's NUMA node they write the page-locked result arrays
-  // (which live on that node) locally -- 5.4 against 7.3 ms per 256-pair call on one box (round 3) -- but on a host shared
-  // with other jobs that node's CPUs may be the busy ones: 8.5 ms bound against 5.3 ms unbound on another box (round 4).
-  // So the first large calls of a context TRY both (call 2 bound, call 3 unbound; call 1 is cold and not looked at) and the
-  // faster stays; GPC_HIP_NUMA_BIND=1 / GPC_HIP_NO_NUMA_BIND=1 force either.
-  int bind_mode = 0;              // 0: bound to the GPU's node, 1: unbound
-  int bind_calls = 0;             // large calls seen so far (exploration state)
-  double bind_ms[2] = {0.0, 0.0}; // ms per pair of the exploration calls
-  bool bind_forced = false;
   bool have_node_cpus = false;    // CPUs of the NUMA node this GPU hangs off (from sysfs), within the process's affinity mask
   cpu_set_t node_cpus;
   int numa_node = -1;
@@ -367,7 +354,6 @@ int usable_cpus() {
 // what the process may use.  GPC_HIP_NO_NUMA_BIND leaves the workers unbound.
 void find_gpu_node_cpus(gpc_hip_ctx* c) {
   c->have_node_cpus = false;
-  if (getenv("GPC_HIP_NUMA_BIND")) c->bind_forced = true;   // always bound (bind_mode 0)
   if (getenv("GPC_HIP_NO_NUMA_BIND")) return;
   char bdf[64] = {0};
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, c->device) != hipSuccess) return;
@@ -403,39 +389,6 @@ void find_gpu_node_cpus(gpc_hip_ctx* c) {
   if (CPU_COUNT(&c->node_cpus) < 2) return;  // nothing sensible to bind to
   c->numa_node = node;
   c->have_node_cpus = true;
-}
-
-// Page-locked host memory ON THE GPU'S NUMA NODE.  hipHostMalloc places its pages where the calling thread's memory
-// policy says -- by default the node the caller happens to run on -- and a staging or result buffer on the other socket makes
-// every DMA and every expansion store cross the socket link: boxes whose GPU hangs off node 0 gave 5.6-6.7 ms per 256-pair
-// call where boxes with the GPU on node 1 gave 5.3 (the bench's Python thread sat on node 1 either way).  The policy is set
-// to "prefer the GPU's node" for the duration of the allocation only (set_mempolicy, no libnuma needed) and put back.
-struct PreferGpuNode {
-  bool on = false;
-  int old_mode = 0;
-  unsigned long old_mask[16] = {0};
-  explicit PreferGpuNode(const gpc_hip_ctx* c) {
-    if (!c || !c->have_node_cpus || c->numa_node < 0 || c->numa_node >= 1024) return;
-    if (syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0ul) != 0) return;
-    unsigned long mask[16] = {0};
-    mask[c->numa_node / (8 * sizeof(unsigned long))] = 1ul << (c->numa_node % (8 * sizeof(unsigned long)));
-    on = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8) == 0;
-  }
-  ~PreferGpuNode() {
-    if (on) (void)syscall(SYS_set_mempolicy, old_mode, old_mode == 0 ? nullptr : old_mask, old_mode == 0 ? 0ul : sizeof(old_mask) * 8);
-  }
-};
-int host_malloc_near_gpu(gpc_hip_ctx* c, void** p, size_t bytes, unsigned flags) {
-  PreferGpuNode prefer(c);
-  HIPCHK(c, hipHostMalloc(p, bytes, flags));
-  if (getenv("GPC_HIP_DEBUG")) {  // where did the pages land?  (move_pages with no target nodes only reports)
-    void* pages[2] = {*p, (char*)*p + (bytes > 4096 ? bytes - 4096 : 0)};
-    int status[2] = {-9, -9};
-    (void)syscall(SYS_move_pages, 0, 2ul, pages, nullptr, status, 0);
-    fprintf(stderr, "[gpc_hip] %zu page-locked bytes: first / last page on NUMA node %d / %d (GPU on node %d, this thread on CPU %d, policy %s)\n",
-            bytes, status[0], status[1], c->numa_node, sched_getcpu(), prefer.on ? "preferred" : "unchanged");
-  }
-  return GPC_OK;
 }
 
 // Worker threads gpc_hip_match_batch may start for the host expansion when nobody said how many: the process's CPUs
@@ -1650,7 +1603,7 @@ int gpc_hip_set_arithmetic(gpc_hip_ctx* c, int mode) {
 int gpc_hip_host_alloc(gpc_hip_ctx* c, uint64_t bytes, void** ptr) {
   if (!c || !ptr || bytes == 0) return GPC_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  CHK(host_malloc_near_gpu(c, ptr, (size_t)bytes, hipHostMallocDefault));
+  HIPCHK(c, hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
   return GPC_OK;
 }
 
@@ -1937,7 +1890,7 @@ static int pinned_counts(gpc_hip_ctx* c, int npairs) {
   if (c->h_cnt) HIPCHK(c, hipHostFree(c->h_cnt));
   c->h_cnt = nullptr;
   c->h_cnt_cap = 0;
-  CHK(host_malloc_near_gpu(c, (void**)&c->h_cnt, sizeof(int32_t) * 3 * (size_t)npairs, hipHostMallocDefault));
+  HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, sizeof(int32_t) * 3 * (size_t)npairs, hipHostMallocDefault));
   c->h_cnt_cap = (size_t)npairs * 3;
   return GPC_OK;
 }
@@ -2206,7 +2159,7 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
     c->h_stage = nullptr;
     c->h_stage_cap = 0;
-    CHK(host_malloc_near_gpu(c, &c->h_stage, stage_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(&c->h_stage, stage_bytes, hipHostMallocDefault));
     c->h_stage_cap = stage_bytes;
   }
   CHK(pinned_counts(c, npairs));
@@ -2226,7 +2179,7 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
       if (c->h_in) HIPCHK(c, hipHostFree(c->h_in));
       c->h_in = nullptr;
       c->h_in_cap = 0;
-      CHK(host_malloc_near_gpu(c, &c->h_in, need, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&c->h_in, need, hipHostMallocDefault));
       c->h_in_cap = need;
     }
   }
@@ -2235,15 +2188,8 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     // shared by both directions being the limit; 14 workers on a 16-CPU share: 10.9 ms)
     int nt = c->expand_threads > 0 ? c->expand_threads : (s->num_threads > 1 ? s->num_threads : default_expand_threads());
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
-    if (c->have_node_cpus && !c->bind_forced && npairs >= 32) {  // exploration: call 1 cold (bound), 2 bound, 3 unbound, then the faster
-      ++c->bind_calls;
-      if (c->bind_calls <= 2) c->bind_mode = 0;
-      else if (c->bind_calls == 3) c->bind_mode = 1;
-      else if (c->bind_calls == 4) c->bind_mode = (c->bind_ms[1] < 0.93 * c->bind_ms[0]) ? 1 : 0;  // unbound must win clearly
-    }
-    c->pool.start(nt, (c->have_node_cpus && c->bind_mode == 0) ? &c->node_cpus : nullptr);
+    c->pool.start(nt, c->have_node_cpus ? &c->node_cpus : nullptr);
   }
-  const auto t_call0 = std::chrono::steady_clock::now();
   uint8_t* d_pk = (uint8_t*)c->packed.p;
   uint8_t* h_pk = (uint8_t*)c->h_stage;
   int status = GPC_OK;
@@ -2358,8 +2304,6 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
   c->pool.wait_all();
   HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->have_node_cpus && !c->bind_forced && npairs >= 32 && (c->bind_calls == 2 || c->bind_calls == 3))
-    c->bind_ms[c->bind_calls - 2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count() / npairs;
   CHK(check_join_err(c));
   return status;
 }
@@ -2382,7 +2326,6 @@ int gpc_hip_match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_
 
 int gpc_hip_host_threads(const gpc_hip_ctx* c) { return c ? c->pool.size() : 0; }
 int gpc_hip_host_numa_node(const gpc_hip_ctx* c) { return (c && c->have_node_cpus) ? c->numa_node : -1; }
-int gpc_hip_host_workers_bound(const gpc_hip_ctx* c) { return (c && c->have_node_cpus && c->bind_mode == 0) ? 1 : 0; }
 
 int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H,
                        const gpc_settings* s, gpc_support* out, int cap, int* n_out, int* n_cand_l,

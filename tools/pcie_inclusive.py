@@ -128,7 +128,7 @@ def host_info(ctx):
     try:
         info["expand_threads"] = int(ctx.L.gpc_hip_host_threads(ctx.h))
         info["gpu_numa_node"] = int(ctx.L.gpc_hip_host_numa_node(ctx.h))
-        info["workers_bound_to_gpu_node"] = bool(ctx.L.gpc_hip_host_workers_bound(ctx.h))   # (what the context settled on)
+        info["workers_bound_to_gpu_node"] = info["gpu_numa_node"] >= 0
     except Exception:
         pass
     return info
