@@ -79,17 +79,20 @@ __device__ __forceinline__ uint32_t swar_ge(uint32_t a, uint32_t b) {
 
 // _mm_subs_epi8(b, tau) on 4 packed bytes: signed saturating subtract (filter.hpp:649-651).
 // An int8 value placed in the HIGH byte of a 16-bit lane saturates under a saturating 16-bit
-// subtract exactly when the int8 subtraction would (v_pk_sub_i16 with clamp), so the even and
-// the odd bytes take one packed op each: perm, pk_sub, and, pk_sub, perm = 5 VALU per 4 pixels.
-// tau_hi = (tau & 0xFF) << 8 in both 16-bit halves.
+// subtract exactly when the int8 subtraction would (v_pk_sub_i16 with clamp), whatever the low
+// byte holds: the lane is s * 256 + g with 0 <= g <= 255, minus tau * 256 it leaves [-32768, 32767]
+// exactly when s - tau leaves [-128, 127], and a saturated lane (0x7FFF / 0x8000) has the saturated
+// int8 in its high byte.  So the odd bytes are subtracted where they lie (the even byte below each is
+// the garbage g), the even bytes after one shift (b1 below b2), and one permute picks the four high
+// bytes: shl, pk_sub, pk_sub, perm = 4 VALU per 4 pixels (round 3 isolated both byte sets first: 5, two of
+// them half-rate permutes).  tau_hi = (tau & 0xFF) << 8 in both 16-bit halves.
 typedef short gpc_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
-  const uint32_t xe = __builtin_amdgcn_perm(0u, b, 0x020C000Cu);  // [0, b0, 0, b2]
-  const uint32_t xo = b & 0xFF00FF00u;                             // [0, b1, 0, b3]
+  const uint32_t xe = b << 8;  // lanes [b0 : 0], [b2 : b1]
   gpc_short2 t, e, o;
   __builtin_memcpy(&t, &tau_hi, 4);
   __builtin_memcpy(&e, &xe, 4);
-  __builtin_memcpy(&o, &xo, 4);
+  __builtin_memcpy(&o, &b, 4);   // lanes [b1 : b0], [b3 : b2]
   e = __builtin_elementwise_sub_sat(e, t);
   o = __builtin_elementwise_sub_sat(o, t);
   uint32_t re, ro;
@@ -98,15 +101,34 @@ __device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
   return __builtin_amdgcn_perm(ro, re, 0x07030501u);  // high bytes back in place: [e.1, o.1, e.3, o.3]
 }
 
-// unsigned saturating add of a uniform constant to 4 packed bytes (same high-byte trick, v_pk_add_u16 clamp)
+// ~_mm_subs_epi8(b, tau): the bytewise complement of the saturated difference, for -127 <= tau <= 127.  ~s = -s - 1 maps
+// [-128, 127] onto itself in reverse order, so ~clamp(s - tau) = clamp((tau - 1) - s): the same two packed subtracts with
+// the constant as the minuend.  Lane arithmetic: ((tau - 1) * 256 + 255) - (s * 256 + g) = (tau - 1 - s) * 256 + (255 - g),
+// 0 <= 255 - g <= 255: the high-byte argument of subs_epi8x4 again.  tau_rev = that minuend in both 16-bit halves
+// (tau = -128 has no such minuend in 16 bits: the caller complements subs_epi8x4's result instead).
+__device__ __forceinline__ uint32_t subs_epi8x4_not(uint32_t b, uint32_t tau_rev) {
+  const uint32_t xe = b << 8;
+  gpc_short2 t, e, o;
+  __builtin_memcpy(&t, &tau_rev, 4);
+  __builtin_memcpy(&e, &xe, 4);
+  __builtin_memcpy(&o, &b, 4);
+  e = __builtin_elementwise_sub_sat(t, e);
+  o = __builtin_elementwise_sub_sat(t, o);
+  uint32_t re, ro;
+  __builtin_memcpy(&re, &e, 4);
+  __builtin_memcpy(&ro, &o, 4);
+  return __builtin_amdgcn_perm(ro, re, 0x07030501u);
+}
+
+// unsigned saturating add of a uniform constant to 4 packed bytes (same high-byte argument: the lane x * 256 + g plus
+// t * 256 passes 65535 exactly when x + t passes 255; v_pk_add_u16 clamp)
 typedef unsigned short gpc_ushort2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t uaddsat_x4(uint32_t x, uint32_t t_hi) {
-  const uint32_t xe = __builtin_amdgcn_perm(0u, x, 0x020C000Cu);
-  const uint32_t xo = x & 0xFF00FF00u;
+  const uint32_t xe = x << 8;
   gpc_ushort2 t, e, o;
   __builtin_memcpy(&t, &t_hi, 4);
   __builtin_memcpy(&e, &xe, 4);
-  __builtin_memcpy(&o, &xo, 4);
+  __builtin_memcpy(&o, &x, 4);
   e = __builtin_elementwise_add_sat(e, t);
   o = __builtin_elementwise_add_sat(o, t);
   uint32_t re, ro;
@@ -164,10 +186,24 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
   constexpr int D = HT_PIPE + 1;
   uint32_t a[D][RPW], b[D][RPW];
   const uint32_t* base = reinterpret_cast<const uint32_t*>(tile + lanebase);
+#ifndef HT_PACKED_OFFS
+  // the group's tap offsets (and, TAU, the words its tau bytes lie in) in one scalar load ahead of the tests: fetched where
+  // each test needs them, the branches a TAU test takes keep the compiler from merging the loads, and every test then
+  // waits out a scalar-cache round trip (s_load_dwordx2 + s_waitcnt lgkmcnt(0)) in front of its LDS reads.  boff[] has 64
+  // entries and tau8[] 8 words whatever T is, so slots past `cnt` are readable.
+  uint32_t goff[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; ++i) goff[i] = fp->boff[2 * t0 + i];
+  uint32_t gtau[3] = {0u, 0u, 0u};
+  if (TAU && !NAIVE) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gtau[i] = (uint32_t)fp->tau8[min((t0 >> 2) + i, 7)];
+  }
+#endif
   auto load = [&](int i, int slot) {
 #ifndef HT_PACKED_OFFS  // (byte offsets, two words per test: 404-405 vs 408-414 us per 256 pairs against the packed dword offsets)
-    const uint32_t* pa = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + fp->boff[2 * (t0 + i)]);
-    const uint32_t* pb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + fp->boff[2 * (t0 + i) + 1]);
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + goff[2 * i]);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + goff[2 * i + 1]);
 #else
     const int packed = fp->off[t0 + i];
     const uint32_t* pa = base + (int)(int16_t)(packed & 0xFFFF);
@@ -188,25 +224,46 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
     __builtin_amdgcn_sched_barrier(0);
     if (i < cnt) {
       // SSE arithmetic: the byte of tau (packed four per word); Naive: the int
+#ifndef HT_PACKED_OFFS
+      const int tau = !TAU ? 0 : (NAIVE ? fp->tau[t0 + i] : (int)((gtau[((t0 + i) >> 2) - (t0 >> 2)] >> (((t0 + i) & 3) * 8)) & 0xFFu));
+#else
       const int tau = !TAU ? 0 : (NAIVE ? fp->tau[t0 + i] : (int)((((uint32_t)fp->tau8[(t0 + i) >> 2]) >> (((t0 + i) & 3) * 8)) & 0xFFu));
+#endif
+      if (TAU && !NAIVE && tau != 0) {
+        // tau is wave-uniform (a scalar load) and the loop is unrolled, so this is a scalar branch per test (a test whose tau
+        // is 0 -- _mm_subs_epi8(b, 0) = b, 7 of the 30 tests of defaultTauForest.txt -- takes the plain compare below).
+        // The compare needs one operand complemented: here the saturating subtract delivers ~b' itself (no v_not),
+        // v_lerp_u8(a, ~b', 0) has bit 7 = (a + 255 - b' >= 256) = (a > b') = the code bit, and the plane takes its
+        // complement (the planes hold NOT(code bit), complemented once per row at the end).
+        if (tau != 0x80) {
+          const uint32_t tau_rev = ((uint32_t)((tau - 1) & 0xFF) * 0x01000100u) | 0x00FF00FFu;
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        uint32_t av = a[i % D][r], bv = b[i % D][r];
-        uint32_t ge;
-        if (TAU && NAIVE) {
-          if (tau >= 1) {
-            const uint32_t c = uaddsat_x4(av, (uint32_t)min(tau - 1, 255) * 0x01000100u);
-            ge = ~swar_ge(bv, c);
-          } else {
-            ge = swar_ge(av, uaddsat_x4(bv, (uint32_t)min(-tau, 255) * 0x01000100u));
-          }
+          for (int r = 0; r < RPW; ++r)
+            plane[r] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_rev), 0u),
+                                                   plane[r] >> 1, SW_H, 0x4E);
         } else {
-          // tau is wave-uniform (a scalar load) and the loop is unrolled: a test whose tau is 0 -- _mm_subs_epi8(b, 0) = b,
-          // 7 of the 30 tests of defaultTauForest.txt -- skips the 5 operations of the saturating subtract behind a scalar branch
-          if (TAU && tau != 0) bv = subs_epi8x4(bv, (uint32_t)(tau & 0xFF) * 0x01000100u);
-          ge = swar_ge(av, bv);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+            plane[r] = __builtin_amdgcn_bitop3_b32(swar_ge(a[i % D][r], subs_epi8x4(b[i % D][r], 0x80008000u)), plane[r] >> 1,
+                                                   SW_H, 0xE4);
         }
-        plane[r] = __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          uint32_t av = a[i % D][r], bv = b[i % D][r];
+          uint32_t ge;
+          if (TAU && NAIVE) {
+            if (tau >= 1) {
+              const uint32_t c = uaddsat_x4(av, (uint32_t)min(tau - 1, 255) * 0x01000100u);
+              ge = ~swar_ge(bv, c);
+            } else {
+              ge = swar_ge(av, uaddsat_x4(bv, (uint32_t)min(-tau, 255) * 0x01000100u));
+            }
+          } else {
+            ge = swar_ge(av, bv);
+          }
+          plane[r] = __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -69,15 +69,20 @@ def test_hash_codes_dense(ctx, oracle, forest_paths, W, H, forest):
             assert np.array_equal(ctx.hash_codes(smooth, g), oracle.hash(smooth, g, f))
 
 
-def test_hash_codes_32_tests_full_tau_range(ctx, oracle):
+@pytest.mark.parametrize("taus", ["random", "edges"])
+def test_hash_codes_32_tests_full_tau_range(ctx, oracle, taus):
+    """32 tests whose tau covers int8: random values, and every value at which the saturating subtract changes regime
+    (-128 has a code path of its own in k_hash, +-127 / +-1 / 0 are its neighbours' limits)."""
     W, H = 160, 100
     rng = np.random.default_rng(5)
+    edge = [-128, -127, -126, -1, 0, 1, 2, 126, 127, -128, 64, -64, 127, -127, 1, -1]
     lines = ["4"]
     for fern in range(4):
         lines.append("%d l 8" % fern)
         for t in range(8):
             ix, iy, jx, jy = rng.integers(-13, 14, 4)
-            lines.append("%d %d %d %d %d %d" % (t, ix, iy, jx, jy, rng.integers(-128, 128)))
+            tau = rng.integers(-128, 128) if taus == "random" else edge[(fern * 8 + t) % len(edge)]
+            lines.append("%d %d %d %d %d %d" % (t, ix, iy, jx, jy, tau))
     text = "\n".join(lines)
     import opengpc_amd as g
     st, fm = g.parse_forest(text, W, H)
@@ -87,6 +92,11 @@ def test_hash_codes_32_tests_full_tau_range(ctx, oracle):
     for img in images(W, H, 6)[:3]:
         smooth, grad, _ = oracle.preprocess(img, 5)
         assert np.array_equal(ctx.hash_codes(smooth, grad), oracle.hash(smooth, grad, f))
+        # the image itself as the smoothed plane: every byte value (0 / 127 / 128 / 255 beside each other) meets every tau
+        assert np.array_equal(ctx.hash_codes(img, grad), oracle.hash(img, grad, f))
+    ramp = ((np.arange(W)[None, :] * 5 + np.arange(H)[:, None] * 3) % 256).astype(np.uint8)
+    grad = np.full((H, W), 9, np.uint8)
+    assert np.array_equal(ctx.hash_codes(ramp, grad), oracle.hash(ramp, grad, f))
 
 
 @pytest.mark.parametrize("case_idx", [0, 1], ids=["96x64", "1024x436"])

@@ -1,0 +1,62 @@
+"""The byte arithmetic k_hash.h builds from 16-bit packed operations, checked exhaustively in numpy (no GPU): these are the
+identities its comments claim, for every byte pair and every tau.  Reference semantics: _mm_subs_epi8 (filter.hpp:649-651)."""
+import numpy as np
+
+
+def sat16(x):
+    return np.clip(x, -32768, 32767)
+
+
+def lanes(hi, lo):
+    """signed 16-bit lane with `hi` in the high byte (as int8) and `lo` (0..255) below it"""
+    return hi.astype(np.int64) * 256 + lo.astype(np.int64)
+
+
+def high_byte(lane):
+    return (lane >> 8).astype(np.int64)        # arithmetic shift: the int8 in the high byte
+
+
+S = np.arange(-128, 128, dtype=np.int64)[:, None]     # the int8 operand
+G = np.arange(0, 256, dtype=np.int64)[None, :]        # whatever byte lies below it in the lane
+
+
+def test_saturating_subtract_in_the_high_byte_ignores_the_low_byte():
+    for tau in range(-128, 128):
+        want = np.clip(S - tau, -128, 127) + 0 * G
+        got = high_byte(sat16(lanes(S, G) - tau * 256))
+        assert np.array_equal(got, want), tau
+
+
+def test_complemented_saturating_subtract_with_the_constant_as_minuend():
+    """subs_epi8x4_not: ~clamp(s - tau) = high byte of sat16(((tau - 1) * 256 + 255) - lane) for -127 <= tau <= 127."""
+    for tau in range(-127, 128):
+        want = ~np.clip(S - tau, -128, 127) + 0 * G
+        minuend = (tau - 1) * 256 + 255
+        assert -32768 <= minuend <= 32767
+        got = high_byte(sat16(minuend - lanes(S, G)))
+        assert np.array_equal(got, want), tau
+
+
+def test_unsigned_saturating_add_in_the_high_byte_ignores_the_low_byte():
+    X = np.arange(0, 256, dtype=np.int64)[:, None]
+    for t in range(0, 256):
+        want = np.minimum(X + t, 255) + 0 * G
+        got = np.minimum(X * 256 + G + t * 256, 65535) >> 8
+        assert np.array_equal(got, want), t
+
+
+def test_lerp_compare_polarities():
+    """v_lerp_u8(x, y, c) = (x + y + c) >> 1 per byte on a 9-bit sum.  (b, ~a, 1): bit 7 = b >= a.  (a, ~b, 0): bit 7 = a > b."""
+    a = np.arange(256, dtype=np.int64)[:, None]
+    b = np.arange(256, dtype=np.int64)[None, :]
+    assert np.array_equal((((b + (255 - a) + 1) >> 1) >> 7) & 1, (b >= a).astype(np.int64))
+    assert np.array_equal((((a + (255 - b) + 0) >> 1) >> 7) & 1, (a > b).astype(np.int64))
+
+
+def test_bitop3_tables():
+    """v_bitop3_b32 table index = a * 4 + b * 2 + c.  0xE4: c ? a : b.  0x4E: c ? ~a : b."""
+    for tt, f in ((0xE4, lambda a, b, c: a if c else b), (0x4E, lambda a, b, c: (1 - a) if c else b)):
+        for a in (0, 1):
+            for b in (0, 1):
+                for c in (0, 1):
+                    assert (tt >> (a * 4 + b * 2 + c)) & 1 == f(a, b, c)
