@@ -37,14 +37,13 @@ template <bool NAIVE>
 __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, long n, int W, int H,
                                              int r, int x0, PreRow& o) {
   int p[PP_PX + 2];
-  if (r < 0 || r >= H) {
-#pragma unroll
-    for (int i = 0; i < PP_PX + 2; ++i) p[i] = 0;
-    // linear addressing: the byte "left of" column 0 of the row below the image is the image's
-    // last byte (the naive filters' window at position (H-1)*W reaches it)
-    if (r == H && x0 == 0) p[0] = raw[n - 1];
-  } else {
-    const int k = r * W + x0;  // (an image has at most 2^30 pixels, check_dims: 32-bit offsets inside it)
+  // A row outside the image (above the first strip, below the last) reads as zeros.  It is fetched all the same, from the
+  // nearest row inside, and zeroed behind a branch only those strips take: with the zeros as the other arm of an if / else
+  // around the loads, every row of every strip began with ten v_mov of them.
+  const bool outside = r < 0 || r >= H;
+  {
+    const int rc = min(max(r, 0), H - 1);
+    const int k = rc * W + x0;  // (an image has at most 2^30 pixels, check_dims: 32-bit offsets inside it)
     uint32_t w[PP_PX / 4];
 #if !defined(PP_NARROW_LOADS) && PP_PX == 8
     if (k >= 4 && k + 12 <= (int)n) {
@@ -72,6 +71,13 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
     // only at the wave's ends, measured SLOWER on the same box: 230 vs 191 us per 256 pairs)
 #pragma unroll
     for (int i = 0; i < PP_PX; ++i) p[1 + i] = (w[i / 4] >> (8 * (i % 4))) & 0xFF;
+  }
+  if (outside) {
+#pragma unroll
+    for (int i = 0; i < PP_PX + 2; ++i) p[i] = 0;
+    // linear addressing: the byte "left of" column 0 of the row below the image is the image's
+    // last byte (the naive filters' window at position (H-1)*W reaches it)
+    if (r == H && x0 == 0) p[0] = raw[n - 1];
   }
 #pragma unroll
   for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
@@ -159,7 +165,10 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
     img_stats[img * GPC_STAT_STRIDE + GPC_STAT_CODEOR] = 0;
   }
 
-  const int tx = threadIdx.x % PP_TX, ty = threadIdx.x / PP_TX;
+  // a wave is one row strip (PP_TX == 64): its index, and with it every row condition below, is wave-uniform -- said so, the
+  // conditions are scalar branches; left as threadIdx.x / 64 in a VGPR they were exec-masked regions
+  static_assert(PP_TX == 64, "one wave per row strip");
+  const int tx = threadIdx.x % PP_TX, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PP_TX));
   const int x0 = (bx * PP_TX + tx) * PP_PX;
   const int ys = (by * PP_TY + ty) * ROWS;
   if (x0 >= W || ys >= H) return;
