@@ -29,7 +29,18 @@ __device__ __forceinline__ int ninth(int s) { return (int)(__umul24((unsigned)s,
 struct PreRow {
   int h[PP_PX];      // SSE: third(p[x-1]+p[x]+p[x+1]) for the strip's pixels; NAIVE: the plain 3-sum
   int a[PP_PX + 2];  // raw pixels x0-1 .. x0+PP_PX
+  int g[PP_PX / 2];  // SSE: ninth(l + 2c + r) of this row at the strip's Sobel decisions (a row is the "below" of the output row
+                     // above it and the "above" of the one below it: computed once per row, where it was once per use)
 };
+__device__ __forceinline__ void pre_row_sobel_h(PreRow& o) {
+#pragma unroll
+  for (int g8 = 0; g8 < PP_PX / 8; ++g8)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = g8 * 8 + j;
+      o.g[g8 * 4 + j] = ninth(o.a[q] + o.a[q + 2] + 2 * o.a[q + 1]);
+    }
+}
 
 // Linear addressing as in the reference: the byte left of column 0 is the previous row's
 // last byte, the byte right of column W-1 the next row's first (filter.hpp:325-327).
@@ -83,6 +94,7 @@ __device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, lo
   for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
 #pragma unroll
   for (int i = 0; i < PP_PX + 2; ++i) o.a[i] = p[i];
+  if (!NAIVE) pre_row_sobel_h(o);
 }
 
 // The same in two steps (PP_PX == 8): the row's 16 bytes k-4 .. k+11 as they lie in memory -- left neighbour in the top byte
@@ -117,6 +129,7 @@ __device__ __forceinline__ void pre_unpack_row(const uint4 v, PreRow& o) {
   for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
 #pragma unroll
   for (int i = 0; i < PP_PX + 2; ++i) o.a[i] = p[i];
+  if (!NAIVE) pre_row_sobel_h(o);
 }
 
 // raw0/raw1: [npairs][H][W] for side 0 / 1 (raw1 unused when sides == 1)
@@ -130,7 +143,7 @@ __device__ __forceinline__ void pre_unpack_row(const uint4 v, PreRow& o) {
 #ifdef PP_WAVES_PER_EU
 #define PP_OCC __attribute__((amdgpu_waves_per_eu(PP_WAVES_PER_EU, PP_WAVES_PER_EU)))
 #else
-#define PP_OCC
+#define PP_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 template <bool NAIVE, int ROWS, bool BITS = false>
 __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
@@ -267,11 +280,11 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int q = g8 * 8 + j;
-          const int l0 = up.a[q], c0 = up.a[q + 1], r0 = up.a[q + 2];
+          const int l0 = up.a[q], r0 = up.a[q + 2];
           const int l1 = mid.a[q], r1 = mid.a[q + 2];
-          const int l2 = dn.a[q], c2 = dn.a[q + 1], r2 = dn.a[q + 2];
+          const int l2 = dn.a[q], r2 = dn.a[q + 2];
           const int gx = ninth(l0 + l2 + 2 * l1) - ninth(r0 + r2 + 2 * r1);
-          const int gy = ninth(l0 + r0 + 2 * c0) - ninth(l2 + r2 + 2 * c2);
+          const int gy = up.g[g8 * 4 + j] - dn.g[g8 * 4 + j];
           const bool edge = gx * gx + gy * gy > thr_sq;
           if (BITS) gm |= edge ? (3u << (2 * j)) : 0u;  // decision j shows on pixels 2j and 2j + 1
           const uint32_t e = edge ? 0xFFFFu : 0u;
