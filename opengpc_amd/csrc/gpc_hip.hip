@@ -527,11 +527,12 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
   // threshold^2 passes through _mm_set1_epi16 in the SSE build (filter.hpp:418); sobelNaive keeps the int (:159)
   const int thr_sq = c->naive ? (thr & 0xFF) * (thr & 0xFF) : (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
-  // 8 rows per thread read every raw row 1.25 times; launches that would not fill the device
-  // (a single pair: 56 workgroups) use 2 rows per thread instead -- 4x the workgroups, shorter chains
+  // 14 rows per thread read every raw row 1.14 times; launches that would not fill the device with such strips
+  // (fewer than 1024 workgroups: 4 per CU) use 6 rows per thread, and those that still would not (a single pair) 2 --
+  // more workgroups, shorter chains
   const int gx = (W / PP_PX + PP_TX - 1) / PP_TX;
-  const bool small = (long)gx * ((H + PP_TY * PP_ROWS - 1) / (PP_TY * PP_ROWS)) * nimg < 1024;
-  const int rows = small ? PP_ROWS_SMALL : PP_ROWS;
+  auto blocks_with = [&](int r) { return (long)gx * ((H + PP_TY * r - 1) / (PP_TY * r)) * nimg; };
+  const int rows = blocks_with(PP_ROWS) >= 1024 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL);
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
   // (the SSE=OFF arithmetic keeps the byte image: its 32-test codes need the candidate BYTES in the matchers, wide_codes())
@@ -541,13 +542,16 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
 #define LAUNCH_PRE(NAIVE, ROWS, BITS)                                                                        \
   hipLaunchKernelGGL((gpc::k_preprocess<NAIVE, ROWS, BITS>), grid, dim3(PP_TX * PP_TY), 0, c->stream, d_raw0, d_raw1, \
                      (uint8_t*)c->smooth.p, (uint8_t*)c->grad.p, W, H, sides, thr_sq, (int32_t*)c->stats.p)
-  if (c->naive) {
-    if (small) LAUNCH_PRE(true, PP_ROWS_SMALL, false); else LAUNCH_PRE(true, PP_ROWS, false);
-  } else if (c->grad_is_bits) {
-    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL, true); else LAUNCH_PRE(false, PP_ROWS, true);
-  } else {
-    if (small) LAUNCH_PRE(false, PP_ROWS_SMALL, false); else LAUNCH_PRE(false, PP_ROWS, false);
-  }
+#define LAUNCH_PRE_ROWS(NAIVE, BITS)                                  \
+  do {                                                                \
+    if (rows == PP_ROWS) LAUNCH_PRE(NAIVE, PP_ROWS, BITS);            \
+    else if (rows == PP_ROWS_MID) LAUNCH_PRE(NAIVE, PP_ROWS_MID, BITS); \
+    else LAUNCH_PRE(NAIVE, PP_ROWS_SMALL, BITS);                      \
+  } while (0)
+  if (c->naive) LAUNCH_PRE_ROWS(true, false);
+  else if (c->grad_is_bits) LAUNCH_PRE_ROWS(false, true);
+  else LAUNCH_PRE_ROWS(false, false);
+#undef LAUNCH_PRE_ROWS
 #undef LAUNCH_PRE
   HIPCHK(c, hipGetLastError());
   return GPC_OK;

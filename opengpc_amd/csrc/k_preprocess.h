@@ -5,7 +5,7 @@
 //
 // HBM-bound streaming kernel: 1 byte read, 2 bytes written per pixel.  One thread owns a
 // PP_PX (8)-pixel-wide column strip (one 16-byte load per row that includes both neighbour bytes, 8-byte stores) and marches
-// down ROWS (8; 2 for small launches) rows with a rolling 3-row window in registers, so every raw
+// down ROWS (14; 6 or 2 for smaller launches) rows with a rolling 3-row window in registers, so every raw
 // row is read (ROWS+2)/ROWS times.  An 8-pixel group is the natural unit of the reference's Sobel
 // lane-duplication quirk (4 decisions shown twice per 8 pixels).
 #pragma once
@@ -14,8 +14,9 @@
 #ifndef PP_PX
 #define PP_PX 8        // pixels per thread along x (8 or 16); measured on MI355X: 8 -> 29.5 us, 16 -> 32.1 us per 64 images
 #endif
-#define PP_ROWS 8      // rows per thread (PP_ROWS_SMALL for launches too small to fill the device)
-#define PP_ROWS_SMALL 2
+#define PP_ROWS 14     // rows per thread: a strip of r rows reads r + 2 (8 -> 14: 112 -> 109 us per 256 pairs; 28: the same)
+#define PP_ROWS_MID 6  // launches that would leave workgroup slots empty with the tall strip ...
+#define PP_ROWS_SMALL 2   // ... and with the middle one
 #define PP_TX 64       // threads along x per block
 #define PP_TY 4        // row strips per block
 
@@ -190,19 +191,9 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
   // boxNaive writes up to row H-2, which clearBoundary then zeroes
   const int box_last = NAIVE ? H - 3 : ((H & 1) ? H - 3 : H - 4);
 
-  // columns 0, 1 and W-1 of smooth are cleared (buffer.hpp:637-652): a mask per strip, made once (only the image's first and
-  // last strip have a byte to clear; per pixel and row it was a compare, a scalar OR and a select)
-  uint32_t emask[PP_PX / 4];
-#pragma unroll
-  for (int q = 0; q < PP_PX / 4; ++q) {
-    emask[q] = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int x = x0 + 4 * q + j;
-      if (!(x < 2 || x == W - 1)) emask[q] |= 0xFFu << (8 * j);
-    }
-  }
-
+  // columns 0, 1 and W-1 of smooth are cleared (buffer.hpp:637-652): only the image's first and last strip have a byte to
+  // clear -- a branch those two lanes take (kept as masks the two words cost two registers the kernel does not have)
+  const bool strip_first = x0 == 0, strip_last = x0 + PP_PX == W;
   PreRow rows[3];
 #if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
 #ifndef PP_DEPTH
@@ -244,8 +235,8 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
         const int v = NAIVE ? (up.h[j] + mid.h[j] + dn.h[j]) / 9 : third(up.h[j] + mid.h[j] + dn.h[j]);
         sw[j / 4] |= (uint32_t)v << (8 * (j % 4));
       }
-#pragma unroll
-      for (int q = 0; q < PP_PX / 4; ++q) sw[q] &= emask[q];  // columns 0, 1 and W-1
+      if (strip_first) sw[0] &= 0xFFFF0000u;               // columns 0 and 1
+      if (strip_last) sw[PP_PX / 4 - 1] &= 0x00FFFFFFu;    // column W-1
     }
     if (!row_in) {
     } else if (PP_PX == 16)
