@@ -208,6 +208,7 @@ struct gpc_hip_ctx {
   int fuse_always = 0;        // GPC_HIP_FUSE_ALWAYS: the fused join wherever it is possible, however small the launch (tests, A/B checks)
   int fuse_wgs = 0;           // GPC_HIP_FUSE_WGS: workgroups of the persistent join (tuning; default = what the device holds)
   int fuse_min_pairs = 1;     // GPC_HIP_FUSE_MIN_PAIRS: smaller batches take the two-launch path
+  int pre_rows = 0;           // GPC_HIP_PRE_ROWS = 14 | 6 | 2: that strip height of k_preprocess whatever the launch's size (tests)
   int fuse_shards = 0;        // GPC_HIP_FUSE_SHARDS: ticket counters the pairs are dealt over (0: join_shards() chooses)
   int num_cus = 0;
   std::map<std::pair<const void*, size_t>, int> wgs_per_cu;  // occupancy of the persistent instantiations launched so far, per LDS size
@@ -532,7 +533,8 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   // more workgroups, shorter chains
   const int gx = (W / PP_PX + PP_TX - 1) / PP_TX;
   auto blocks_with = [&](int r) { return (long)gx * ((H + PP_TY * r - 1) / (PP_TY * r)) * nimg; };
-  const int rows = blocks_with(PP_ROWS) >= 1024 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL);
+  const int rows = c->pre_rows ? c->pre_rows
+                               : (blocks_with(PP_ROWS) >= 1024 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL));
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
   // (the SSE=OFF arithmetic keeps the byte image: its 32-test codes need the candidate BYTES in the matchers, wide_codes())
@@ -1502,6 +1504,10 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   c->no_grad_bits = getenv("GPC_HIP_NO_GRAD_BITS") != nullptr;
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
   if (const char* e = getenv("GPC_HIP_HASH_TALL")) c->hash_tall = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("GPC_HIP_PRE_ROWS")) {
+    const int v = atoi(e);
+    if (v == PP_ROWS || v == PP_ROWS_MID || v == PP_ROWS_SMALL) c->pre_rows = v;
+  }
   c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
     const int v = atoi(e);

@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed
 golden vectors.  Integer/byte work: bit-exact.  Disparities are integer-valued floats: exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,41 @@ def test_preprocess(ctx, oracle, W, H, thr):
         assert np.array_equal(s, so)
         assert np.array_equal(g, go)
         assert np.array_equal(m, mo)
+
+
+@pytest.mark.parametrize("rows", [14, 6, 2])
+def test_preprocess_every_strip_height_on_ragged_images(oracle, forest_paths, rows):
+    """k_preprocess has three instantiations (14 / 6 / 2 rows per thread) picked by the launch's size: each forced
+    (GPC_HIP_PRE_ROWS) on heights that leave the last strip -- and the last block of four strips -- partly or wholly empty,
+    in both arithmetics, and through a whole match_pair."""
+    import opengpc_amd as g
+    os.environ["GPC_HIP_PRE_ROWS"] = str(rows)
+    try:
+        c = g.Context(0)
+    finally:
+        del os.environ["GPC_HIP_PRE_ROWS"]
+    try:
+        for (W, H) in [(96, 41), (160, 57), (176, 113), (48, 31), (1936, 59), (272, 171)]:
+            for img in images(W, H, 10 + rows):
+                for thr in (5, 40):
+                    s, gr, m = c.preprocess(img, thr)
+                    so, go, mo = oracle.preprocess(img, thr)
+                    assert np.array_equal(s, so) and np.array_equal(gr, go) and np.array_equal(m, mo), (W, H, thr)
+            c.set_arithmetic(True)     # the reference built with SSE=OFF: k_preprocess<true, rows>
+            for img in images(W, H, 20 + rows)[:2]:
+                s, gr, m = c.preprocess(img, 5)
+                so, go, mo = oracle.preprocess_naive(img, 5)
+                assert np.array_equal(s, so) and np.array_equal(gr, go) and np.array_equal(m, mo), (W, H, "naive")
+            c.set_arithmetic(False)
+        rc, f = oracle.read_forest(forest_paths["zero"], 176, 113)
+        c.load_forest(forest_paths["zero"], 176, 113)
+        base = images(176 + 64, 113, 77)[1]
+        L, R = np.ascontiguousarray(base[:, 32:32 + 176]), np.ascontiguousarray(base[:, 40:40 + 176])
+        so, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings(5, 128, 0, True))
+        sg, n, ncand, st = c.match_pair(L, R, gpu_settings(True, 5, 128, 0))
+        assert st == 0 and (nl, nr) == tuple(ncand) and n == len(so) and np.array_equal(sg, so.astype(sg.dtype))
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("W,H", SHAPES)
