@@ -318,8 +318,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   uint32_t* const r_cnt = rjf_lds + S + S / 2;      // [NB]   bucket counters -> starts
   uint32_t* const d_words = r_cnt + NB;             // [NB-24] ranked words of the row whose output is pending
   uint32_t* const r_key = t_w;                      // [NB]   matched codes of shared buckets (the flag words are dead after the decide phase)
-  const uint32_t keys_lds = (uint32_t)(uintptr_t)t_key;  // low half of the flat address = LDS offset
-  const uint32_t rkey_lds = (uint32_t)(uintptr_t)r_key;
+  // LDS byte offsets for the hand-written loops.  The dynamic block starts where the static variables end (a multiple of 16
+  // here): taken from the low half of the flat address instead, every use paid the address-space cast's null check
+  // (s_cmp_lg_u32 x, -1 + s_cselect_b32: seven pairs per wave and row).
+  static_assert((sizeof(uint32_t) * (12 + NT / 64)) % 16 == 0, "the dynamic block follows the static variables without padding");
+  const uint32_t keys_lds = __builtin_amdgcn_groupstaticsize();
+  const uint32_t rkey_lds = keys_lds + 4u * (uint32_t)S;
 
   // this workgroup's shard of pairs, its size and the multiply-high that divides by it
   int f_shard, f_ps, f_sh;
