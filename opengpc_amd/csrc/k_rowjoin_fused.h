@@ -217,15 +217,25 @@ __device__ __forceinline__ void rjf_finish_pair(int pair, uint32_t total) {
   }
 }
 
+// The hand-written loops narrow EXEC and put it back at their end.  Every call site in this kernel runs with all 64 lanes of
+// the wave active (the workgroup is a whole number of waves, the row loop and everything the loops sit in is wave-uniform), so
+// "back" is all ones: no copy of EXEC saved in front of each of the 16 loops of a row (one instruction each, and a scalar
+// register pair the kernel does not have to spare).  -DRJF_CHECK_EXEC traps where that is not so.
+#ifdef RJF_CHECK_EXEC
+#define RJF_EXEC_ALL "s_mov_b64 exec, -1\n\t"
+#define RJF_ASSERT_EXEC_ALL() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define RJF_EXEC_ALL "s_mov_b64 exec, -1"
+#define RJF_ASSERT_EXEC_ALL() do { } while (0)
+#endif
+
 // rank of code cj among the `cnt` codes keys[s0 ..] of its bucket (cnt > 1: the bucket is shared; lanes with cnt <= 1 keep
 // rank = s0).  The lanes still walking narrow EXEC with v_cmpx and the loop ends on s_cbranch_execnz: one scalar
 // instruction per round where the compiler's structurised divergent loop spent more scalar than vector instructions.
 // keys_lds = LDS byte offset of the code array.
 __device__ __forceinline__ uint32_t rjf_walk(uint32_t keys_lds, uint32_t s0, uint32_t cnt, uint32_t cj) {
   uint32_t rank = s0, addr, k;
-  unsigned long long sv;
   asm volatile(
-      "s_mov_b64 %[sv], exec\n\t"
       "v_cmpx_lt_u32_e32 vcc, 1, %[cnt]\n\t"
       "s_cbranch_execz 2f\n\t"
       "v_lshl_add_u32 %[addr], %[s0], 2, %[base]\n"
@@ -239,8 +249,8 @@ __device__ __forceinline__ uint32_t rjf_walk(uint32_t keys_lds, uint32_t s0, uin
       "v_cmpx_ne_u32_e32 vcc, 0, %[cnt]\n\t"
       "s_cbranch_execnz 1b\n"
       "2:\n\t"
-      "s_mov_b64 exec, %[sv]"
-      : [rank] "+v"(rank), [cnt] "+v"(cnt), [addr] "=&v"(addr), [k] "=&v"(k), [sv] "=&s"(sv)
+      RJF_EXEC_ALL
+      : [rank] "+v"(rank), [cnt] "+v"(cnt), [addr] "=&v"(addr), [k] "=&v"(k)
       : [s0] "v"(s0), [cj] "v"(cj), [base] "s"(keys_lds)
       : "vcc", "memory");
   return rank;
@@ -250,9 +260,7 @@ __device__ __forceinline__ uint32_t rjf_walk(uint32_t keys_lds, uint32_t s0, uin
 // o == cur (and cur != 0) says the carried key met a copy of itself: that key occurs twice among the left records.
 __device__ __forceinline__ void rjf_insert_chain(uint32_t keys_lds, uint32_t& cur, uint32_t& o, uint32_t h, uint32_t smask) {
   uint32_t addr;
-  unsigned long long sv;
   asm volatile(
-      "s_mov_b64 %[sv], exec\n\t"
       "v_cmpx_ne_u32_e32 vcc, 0, %[cur]\n\t"       // lanes without a record never probe on
       "v_cmpx_ne_u32_e32 vcc, 0, %[o]\n\t"
       "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
@@ -268,10 +276,32 @@ __device__ __forceinline__ void rjf_insert_chain(uint32_t keys_lds, uint32_t& cu
       "v_cmpx_ne_u32_e32 vcc, %[o], %[cur]\n\t"
       "s_cbranch_execnz 1b\n"
       "2:\n\t"
-      "s_mov_b64 exec, %[sv]"
-      : [cur] "+v"(cur), [o] "+v"(o), [h] "+v"(h), [addr] "=&v"(addr), [sv] "=&s"(sv)
+      RJF_EXEC_ALL
+      : [cur] "+v"(cur), [o] "+v"(o), [h] "+v"(h), [addr] "=&v"(addr)
       : [smask] "s"(smask), [base] "s"(keys_lds)
       : "vcc", "memory");
+}
+
+// rj_find_chain (k_rowjoin.h) for this kernel's call sites, where every lane of the wave is active
+__device__ __forceinline__ uint32_t rjf_find_chain(uint32_t keys_lds, uint32_t k, uint32_t& kk, uint32_t h, uint32_t smask) {
+  uint32_t addr;
+  asm volatile(
+      "v_cmpx_gt_u32_e32 vcc, %[kk], %[k]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_add_u32_e32 %[h], 1, %[h]\n\t"
+      "v_and_b32_e32 %[h], %[smask], %[h]\n\t"
+      "v_lshl_add_u32 %[addr], %[h], 2, %[base]\n\t"
+      "ds_read_b32 %[kk], %[addr]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmpx_gt_u32_e32 vcc, %[kk], %[k]\n\t"
+      "s_cbranch_execnz 1b\n"
+      "2:\n\t"
+      RJF_EXEC_ALL
+      : [kk] "+v"(kk), [h] "+v"(h), [addr] "=&v"(addr)
+      : [k] "v"(k), [smask] "s"(smask), [base] "s"(keys_lds)
+      : "vcc", "memory");
+  return h;
 }
 
 // Home slot of key k: its hash -- or, for a pixel slot without a record (k == 0), a slot of the lane's own (idx): the
@@ -493,6 +523,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
         uint32_t cur = kl[j], o = old[j];
+        RJF_ASSERT_EXEC_ALL();
         rjf_insert_chain(keys_lds, cur, o, h0l[j], smask);
         const bool met = kl[j] && o == cur;
         if (met && cur == kl[j]) ldup |= 1u << j;
@@ -550,7 +581,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
           uint32_t kk = kl[j] ? f0l[j] : 0u;
-          hl[j] = rj_find_chain(keys_lds, kl[j], kk, h0l[j], smask);  // a left code is always found
+          RJF_ASSERT_EXEC_ALL();
+          hl[j] = rjf_find_chain(keys_lds, kl[j], kk, h0l[j], smask);  // a left code is always found
         }
       }
 #pragma unroll
@@ -565,7 +597,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           for (int j = 0; j < SPT; ++j) {
             const uint32_t hc0 = rj_hash(carried[j], hshift);
             uint32_t kk = carried[j] ? t_key[hc0] : 0u;
-            const uint32_t hc = rj_find_chain(keys_lds, carried[j], kk, hc0, smask);
+            RJF_ASSERT_EXEC_ALL();
+            const uint32_t hc = rjf_find_chain(keys_lds, carried[j], kk, hc0, smask);
             if (carried[j]) atomicOr(&t_w[hc >> 1], F_LDUP << ((hc & 1u) << 4));
 #ifdef RJ_DBG_COUNT
             if (carried[j]) atomicAdd(rjf_args()->err + 3, 1);  // [3] displaced keys that met their copy
@@ -577,7 +610,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
         uint32_t kk = kr[j] ? f0r[j] : 0u;
-          hr[j] = rj_find_chain(keys_lds, kr[j], kk, h0r[j], smask);
+          RJF_ASSERT_EXEC_ALL();
+          hr[j] = rjf_find_chain(keys_lds, kr[j], kk, h0r[j], smask);
         // x goes into the zeroed low bits with the same atomic: several writers only when the code is not unique on
         // the right, and then x is not used
         mv[j] = ((kr[j] && kk == kr[j]) ? (F_RSEEN | (uint32_t)(j * NT + tid)) : 0u) << ((hr[j] & 1u) << 4);
@@ -691,6 +725,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const uint32_t m = (okm >> j) & 1u;
+      RJF_ASSERT_EXEC_ALL();
       const uint32_t rank = rjf_walk(rkey_lds, rb[j], m ? (rs[j] >> 16) : 0u, kl[j] - 1u);
       if (m) d_words[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);  // the ranked words wait in D for the row's place in the output
     }
