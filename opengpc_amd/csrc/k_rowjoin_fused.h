@@ -654,8 +654,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //      own LDS and were cleared with the table: no barrier between deciding and counting)
     uint32_t okm = 0u;  // bit j = pixel slot j is a match
     uint32_t xr[SPT];
+    uint32_t wc = 0u;   // matches of this wave
+    const int disp_high = ka.disp_high, apply_filter = ka.apply_filter;
+#ifndef RJF_OLD_DECIDE
+    if (!WIDE && !tail_row) {
+      // Every row but the one the tail rule applies to (one per pair), straight-line: the four flag halfwords are asked for
+      // together -- a slot without a record has an address of its own and reads it for nothing -- and a match is
+      // (flags & (LDUP | RSEEN | RDUP)) == RSEEN, inside the disparity range, of a slot that holds a record: compares and
+      // mask arithmetic, ~10 instructions per slot.  Written with a branch per condition it was ~36, each slot's read
+      // waited for by itself inside its own EXEC region, and the scalar unit spent more instructions merging lane masks
+      // than the vector unit comparing.
+      uint32_t w[SPT];
+#pragma unroll
+      for (int j = 0; j < SPT; ++j) w[j] = reinterpret_cast<const uint16_t*>(t_w)[hl[j]];
+#pragma unroll
+      for (int j = 0; j < SPT; ++j) {
+        xr[j] = w[j] & F_XMASK;
+        uint32_t has = kl[j];
+        asm volatile("" : "+v"(has));  // (compared afresh: the lane masks of "holds a record" kept from the lookup phase cost spilled scalar pairs)
+        const bool hit = (has != 0u) & ((w[j] & (F_LDUP | F_RSEEN | F_RDUP)) == F_RSEEN);
+        const bool near = (apply_filter == 0) | ((int)__usad((uint32_t)(j * NT + tid), xr[j], 0u) <= disp_high);
+        const bool good = hit & near;
+        wc += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(good));
+        okm |= good ? (1u << j) : 0u;
+      }
+    } else
+#endif
     {
-      const int disp_high = ka.disp_high, apply_filter = ka.apply_filter;
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
         xr[j] = 0u;
@@ -673,6 +698,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
         if (good) okm |= 1u << j;
+        wc += (uint32_t)__popcll(__ballot(good));
       }
     }
     uint32_t rb[SPT], rs[SPT];  // rank bucket / arrival order in it (later: the bucket's first rank / order | matches in the bucket << 16)
@@ -682,12 +708,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       rs[j] = 0u;
       if ((okm >> j) & 1u) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
     }
-    {  // the row's support count, one LDS add per wave that has a match
-      uint32_t wc = 0u;
-#pragma unroll
-      for (int j = 0; j < SPT; ++j) wc += (uint32_t)__popcll(__ballot((okm >> j) & 1u));
-      if (lane == 0 && wc) atomicAdd(&s_cnt, wc);
-    }
+    if (lane == 0 && wc) atomicAdd(&s_cnt, wc);  // the row's support count, one LDS add per wave that has a match
     if (tid == 64) s_ticket = f_nxt;  // (waits for the draw made at the top of the insert phase)
     __syncthreads();  // B3: every match is counted; the flag words are dead from here on (their LDS takes the codes of shared buckets)
     RJ_STAMP(3);
