@@ -492,7 +492,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     // ---- 1. build the ordered table from the left codes; the flag words are cleared meanwhile (the inserts touch keys only)
     uint32_t h0l[SPT];
-    uint32_t ldup = 0u;          // bit j: the code of left pixel slot j occurs at least twice on the left
+    bool ldup[SPT];              // the code of left pixel slot j occurs at least twice on the left (lane masks, not bits of a register:
+                                 // packing them cost a select and an OR per slot, testing them an AND and a compare)
     uint32_t carried[SPT];       // a displaced key this lane saw meet its copy (0: none -- the rule)
 #pragma unroll
     for (int j = 0; j < SPT; ++j) carried[j] = 0u;
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         RJF_ASSERT_EXEC_ALL();
         rjf_insert_chain(keys_lds, cur, o, h0l[j], smask);
         const bool met = kl[j] && o == cur;
-        if (met && cur == kl[j]) ldup |= 1u << j;
-        else if (met) carried[j] = cur;
+        ldup[j] = met && cur == kl[j];
+        if (met && cur != kl[j]) carried[j] = cur;
       }
     }
     if (tail_row) {  // the largest right key of this row (block-uniform branch)
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
 #pragma unroll
       for (int j = 0; j < SPT; ++j)  // a repeated left code: the flag goes onto the code's slot (every copy of it reads that slot)
-        if ((ldup >> j) & 1u) atomicOr(&t_w[hl[j] >> 1], F_LDUP << ((hl[j] & 1u) << 4));
+        if (ldup[j]) atomicOr(&t_w[hl[j] >> 1], F_LDUP << ((hl[j] & 1u) << 4));
       {  // the rare displaced key that met its copy: find its slot like any lookup and flag it (wave-uniform skip otherwise)
         uint32_t anyc = 0u;
 #pragma unroll
