@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     // ---- 3. decide every left candidate, and count the matches per rank bucket right away (the counters have their
     //      own LDS and were cleared with the table: no barrier between deciding and counting)
-    uint32_t okm = 0u;  // bit j = pixel slot j is a match
+    bool ok[SPT];  // pixel slot j is a match (lane masks: as bits of a register every use was an AND and a compare)
     uint32_t xr[SPT];
     uint32_t wc = 0u;   // matches of this wave
     const int disp_high = ka.disp_high, apply_filter = ka.apply_filter;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const bool near = (apply_filter == 0) | ((int)__usad((uint32_t)(j * NT + tid), xr[j], 0u) <= disp_high);
         const bool good = hit & near;
         wc += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(good));
-        okm |= good ? (1u << j) : 0u;
+        ok[j] = good;
       }
     } else
 #endif
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           xr[j] = s_sp_minx;
         }
         if (good && apply_filter) good = abs((int)(j * NT + tid) - (int)xr[j]) <= disp_high;
-        if (good) okm |= 1u << j;
+        ok[j] = good;
         wc += (uint32_t)__popcll(__ballot(good));
       }
     }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int j = 0; j < SPT; ++j) {
       rb[j] = (kl[j] - 1u) >> csh;
       rs[j] = 0u;
-      if ((okm >> j) & 1u) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
+      if (ok[j]) rs[j] = atomicAdd(&r_cnt[rb[j]], 1u);
     }
     if (lane == 0 && wc) atomicAdd(&s_cnt, wc);  // the row's support count, one LDS add per wave that has a match
     if (tid == 64) s_ticket = f_nxt;  // (waits for the draw made at the top of the insert phase)
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // place in r_key nor the walk -- its rank is its bucket's start.
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
-      if ((okm >> j) & 1u) rs[j] |= r_cnt[rb[j]] << 16;
+      if (ok[j]) rs[j] |= r_cnt[rb[j]] << 16;
     if (d_t >= 0) {  // the pending row's records leave (D is rewritten by this row's walk, three barriers on)
       const uint32_t base = s_base;
       rjf_emit_row<NT>(d_words, d_cnt, base, d_pair, GPC_R + d_t, tid);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     block_exscan<SPT, NT, false>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b     (B4, B5)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
-      if ((okm >> j) & 1u) {
+      if (ok[j]) {
         rb[j] = r_cnt[rb[j]];  // the bucket's first rank (the bucket index is not needed again)
         if ((rs[j] >> 16) > 1u) r_key[rb[j] + (rs[j] & 0xFFFFu)] = kl[j] - 1u;  // the code (WIDE: the key-less 0xFFFFFFFF ranks last)
       }
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     RJ_STAMP(5);
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-      const uint32_t m = (okm >> j) & 1u;
+      const bool m = ok[j];
       RJF_ASSERT_EXEC_ALL();
       const uint32_t rank = rjf_walk(rkey_lds, rb[j], m ? (rs[j] >> 16) : 0u, kl[j] - 1u);
       if (m) d_words[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);  // the ranked words wait in D for the row's place in the output
