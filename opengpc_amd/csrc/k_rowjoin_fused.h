@@ -578,12 +578,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         f0r[j] = t_key[h0r[j]];
       }
       uint32_t seen[SPT], mv[SPT];
+      // What a pixel slot searches for: its key -- or, without a record, 0xFFFFFFFF (key | sign mask of key - 1, one OR):
+      // larger than every stored key (codes below 2^31: every arithmetic but WIDE), so its walk never starts, and equal to
+      // none, so it never finds.  (Searching for 0 with a first probe forced to 0 cost a compare, a select and a wait
+      // state per chain.)
+      uint32_t ql[SPT], qr[SPT];
+#pragma unroll
+      for (int j = 0; j < SPT; ++j) {
+        ql[j] = WIDE ? kl[j] : (kl[j] | (uint32_t)((int32_t)(kl[j] - 1u) >> 31));
+        qr[j] = WIDE ? kr[j] : (kr[j] | (uint32_t)((int32_t)(kr[j] - 1u) >> 31));
+      }
       {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-          uint32_t kk = kl[j] ? f0l[j] : 0u;
+          uint32_t kk = WIDE ? (kl[j] ? f0l[j] : 0u) : f0l[j];
           RJF_ASSERT_EXEC_ALL();
-          hl[j] = rjf_find_chain(keys_lds, kl[j], kk, h0l[j], smask);  // a left code is always found
+          hl[j] = rjf_find_chain(keys_lds, ql[j], kk, h0l[j], smask);  // a left code is always found
         }
       }
 #pragma unroll
@@ -610,12 +620,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       uint32_t hr[SPT];
 #pragma unroll
       for (int j = 0; j < SPT; ++j) {
-        uint32_t kk = kr[j] ? f0r[j] : 0u;
-          RJF_ASSERT_EXEC_ALL();
-          hr[j] = rjf_find_chain(keys_lds, kr[j], kk, h0r[j], smask);
+        uint32_t kk = WIDE ? (kr[j] ? f0r[j] : 0u) : f0r[j];
+        RJF_ASSERT_EXEC_ALL();
+        hr[j] = rjf_find_chain(keys_lds, qr[j], kk, h0r[j], smask);
         // x goes into the zeroed low bits with the same atomic: several writers only when the code is not unique on
         // the right, and then x is not used
-        mv[j] = ((kr[j] && kk == kr[j]) ? (F_RSEEN | (uint32_t)(j * NT + tid)) : 0u) << ((hr[j] & 1u) << 4);
+        const bool hit = WIDE ? (kr[j] && kk == kr[j]) : (kk == qr[j]);
+        mv[j] = (hit ? (F_RSEEN | (uint32_t)(j * NT + tid)) : 0u) << ((hr[j] & 1u) << 4);
       }
 #pragma unroll
       for (int j = 0; j < SPT; ++j) seen[j] = atomicOr(&t_w[hr[j] >> 1], mv[j]);

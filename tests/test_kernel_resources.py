@@ -46,7 +46,7 @@ def test_fused_join_every_instantiation(kres):
         wide = name.rstrip(">").endswith("true")                 # WIDE: 32-test SSE=OFF codes, on no BASELINE path
         assert r["sspill"] <= (32 if wide else 12), (name, r)    # (round 3's fused instantiations: 42 .. 55)
     hot = got["gpc::k_row_join_fused<4, 256, false>"]           # the bench's kernel
-    assert hot["sspill"] <= 10 and hot["vgpr"] <= 56, hot     # (9 since the straight-line decide phase keeps more lane masks at once)
+    assert hot["sspill"] <= 10 and hot["vgpr"] <= 62, hot     # (5 spilled scalars, 60 VGPRs since the search keys have registers of their own)
 
 
 def test_two_launch_and_partition_joins_up_to_four_slots(kres):
