@@ -391,13 +391,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   // wave's vector-memory counter is in order, so the wait for these loads then also waits for the acknowledges of the
   // pending row's record stores issued behind them; tools/exp/k_rowjoin_fused_round4_experiments.h.txt).
   uint32_t ncl[SPT], ncr[SPT];
-  auto issue_loads = [&](uint32_t g, uint32_t (&cl)[SPT], uint32_t (&cr)[SPT]) {
+  // the left row of ticket g (the right one lies H * W codes behind it)
+  auto row_of = [&](uint32_t g) -> const uint32_t* {
     const uint32_t q = (f_ps == 1) ? g : (__umulhi(g, f_magic) >> f_sh);
     const int W = ka.W, H = ka.H;
     const int pair = f_shard + ka.nshards * (int)(g - q * (uint32_t)f_ps);
     const long ro = ((long)(pair * 2) * H + (GPC_R + (int)q)) * W;
-    const uint32_t* rl = ka.codes + ro;
-    const uint32_t* rr_ = rl + (long)H * W;
+    return ka.codes + ro;
+  };
+  auto issue_loads = [&](const uint32_t* rl, uint32_t (&cl)[SPT], uint32_t (&cr)[SPT]) {
+    const uint32_t* rr_ = rl + (long)ka.H * ka.W;
     uint32_t lo = threadIdx.x * 4u;
     RJF_OPAQUE_V(lo);
 #pragma unroll
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       cr[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(rr_) + lo + (uint32_t)(j * NT * 4));
     }
   };
-  if (f_g < f_end) issue_loads(f_g, ncl, ncr);
+  if (f_g < f_end) issue_loads(row_of(f_g), ncl, ncr);
 
 #pragma unroll 1
   while (f_g < f_end) {
@@ -759,7 +762,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int j = 0; j < SPT; ++j) {
       const bool m = ok[j];
       RJF_ASSERT_EXEC_ALL();
-      const uint32_t rank = rjf_walk(rkey_lds, rb[j], m ? (rs[j] >> 16) : 0u, kl[j] - 1u);
+      // (rs is 0 for a slot that is no match: its population field says "nothing to walk" by itself)
+      const uint32_t rank = rjf_walk(rkey_lds, rb[j], rs[j] >> 16, kl[j] - 1u);
       if (m) d_words[rank] = (uint32_t)(j * NT + tid) | (xr[j] << 16);  // the ranked words wait in D for the row's place in the output
     }
     // this row is the pending one now; the next row's clear touches neither D nor the flag words
@@ -767,7 +771,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     d_t = f_t;
     d_cnt = f_cnt;
     f_g = f_gn;
-    if (f_g < f_end) issue_loads(f_g, ncl, ncr);
+    // (the row's address worked out right behind the decide barrier, where the ticket is known, instead of here: 531 vs 525 us --
+    // it delays the count's publication and the pending row's records, which the whole pair's look-backs wait for)
+    if (f_g < f_end) issue_loads(row_of(f_g), ncl, ncr);
 #ifdef GPC_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
