@@ -59,6 +59,7 @@ __device__ unsigned long long g_ht_stamps[16];
 #define HT_STAMP_FLUSH()
 #endif
 
+#define HT_FAR 0x40000000   // a byte offset beyond every image (check_dims: at most 2^30 pixels)
 #define SW_H 0x80808080u
 #define SW_M 0x7F7F7F7Fu
 
@@ -354,51 +355,48 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   constexpr int NCHUNK = T_ROWS * QPR;
   constexpr int CPT = (NCHUNK + HT_THREADS - 1) / HT_THREADS;  // chunks per thread
   // chunk -> (window row, chunk in row), byte offset inside a copy: the same for every tile
-  int crow[CPT], cdst[CPT];
+  int crow[CPT], cnxt[CPT], cdst[CPT];
   uint32_t cflag[CPT];  // bit 0: chunk exists, bit 1: it has a right neighbour inside the window
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = tid + i * HT_THREADS;
     const int r = c / QPR, q = c - r * QPR;
-    crow[i] = r * W + q * 16 - HT_APRON + tx0;   // offset of the chunk from the window's first row
+    // offset of the chunk from the window's first row; a chunk this thread does not have lies 2^30 bytes out: beyond any image
+    crow[i] = c < NCHUNK ? r * W + q * 16 - HT_APRON + tx0 : HT_FAR;
+    cnxt[i] = (c < NCHUNK && q + 1 < QPR) ? crow[i] + 16 : HT_FAR;  // the dword behind the chunk -- the row's last chunk has none inside the window
     cdst[i] = r * HT_STRIDE + q * 16;
     cflag[i] = (c < NCHUNK ? 1u : 0u) | (q + 1 < QPR ? 2u : 0u);
   }
   uint4 pv[CPT];
   uint32_t pn[CPT];
   uint32_t pg[RPW];  // gradient bytes of this thread's 4 pixels in its RPW rows of the fetched tile
+  // The image's bytes and its gradient image as BUFFER resources (base, size, no stride): a buffer load outside [0, size)
+  // returns 0 by itself -- the reference's "bytes outside the image read as 0" (its unaligned loads reach above row 0 and
+  // below row H - 1) is the hardware's range check.  Chunks are 16-byte aligned and so is the size: none straddles the end.
+  // (As flat loads behind compares the fetch of a tile was ~150 instructions of EXEC regions and zero moves; it is 25.)
   const uint32_t nbytes = (uint32_t)n;  // an image has at most 2^30 pixels (check_dims): 32-bit offsets
+  const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sm), 0, (int)nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(gr), 0, (int)(GBITS ? nbytes / 8u : nbytes), 0x00020000);
+  // a lane beyond the image's width asks for a gradient word 2^30 bytes out
+  const uint32_t gcol = x0 < W ? (GBITS ? (uint32_t)(x0 & ~15) >> 3 : (uint32_t)x0) : (uint32_t)HT_FAR;
   auto fetch = [&](int ty0) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const int y = ty0 + wave * RPW + r;
-#ifdef HT_EXP_NOGRAD
-      if (GBITS) pg[r] = 0xFFFFu + (uint32_t)(y & 0);
-#else
+      const int y = ty0 + wave * RPW + r;  // (a row below the image: beyond the gradient image's size)
       if (GBITS)  // the group's 16 bits (2-byte aligned: W is a multiple of 16)
-        pg[r] = (x0 < W && y < H) ? (uint32_t)*reinterpret_cast<const uint16_t*>(gr + ((uint32_t)(y * W + (x0 & ~15)) >> 3)) : 0u;
-#endif
+        pg[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs_gr, ((uint32_t)(y * W) >> 3) + gcol, 0, 0);
       else
-        pg[r] = (x0 < W && y < H) ? *reinterpret_cast<const uint32_t*>(gr + (uint32_t)(y * W + x0)) : 0u;
+        pg[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_gr, (uint32_t)(y * W) + gcol, 0, 0);
     }
-    const int base = (ty0 - GPC_R) * W;  // linear addressing like the reference's unaligned loads; bytes outside the buffer read as 0
+    const int base = (ty0 - GPC_R) * W;  // linear addressing like the reference's unaligned loads
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const uint32_t k = (uint32_t)(base + crow[i]);
-      pv[i] = make_uint4(0, 0, 0, 0);
-      pn[i] = 0;
-      if (cflag[i] & 1u) {  // one unsigned compare per range check (k wraps above the buffer when it is negative)
-#if defined(HT_EXP_NOWINDOW)
-        pv[i] = make_uint4(k, k * 3u, k * 5u, k * 7u);
-        pn[i] = k * 11u;
-#elif defined(HT_EXP_NOPN)
-        if (k <= nbytes - 16u) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
-        pn[i] = k * 11u;
-#else
-        if (k <= nbytes - 16u) pv[i] = *reinterpret_cast<const uint4*>(sm + k);
-        if ((cflag[i] & 2u) && k + 16u <= nbytes - 4u) pn[i] = *reinterpret_cast<const uint32_t*>(sm + (k + 16u));
-#endif
-      }
+      const uint32_t k = (uint32_t)(base + crow[i]);  // (negative above the image's first byte: wraps beyond its size)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_sm, k, 0, 0);
+      // (nothing here may touch what the loads return: the wait for them belongs in front of the staging, a tile later)
+      pn[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_sm, (uint32_t)(base + cnxt[i]), 0, 0);
+      pv[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   auto stage = [&]() {  // copy s holds the window shifted left by s bytes (v_alignbyte of neighbouring dwords)
