@@ -44,53 +44,34 @@ __device__ __forceinline__ void pre_row_sobel_h(PreRow& o) {
 }
 
 // Linear addressing as in the reference: the byte left of column 0 is the previous row's
-// last byte, the byte right of column W-1 the next row's first (filter.hpp:325-327).
+// last byte, the byte right of column W-1 the next row's first (filter.hpp:325-327); bytes outside the image read as 0.
+// The image is a BUFFER resource (base, size n, no stride) and a row is ONE 16-byte buffer load at byte r * W + x0 - 4
+// (4-byte aligned): the strip, its left neighbour in the top byte of the first dword, its right one in the low byte of the
+// last.  A buffer load that does not lie inside [0, n) returns 0 -- all of it, also the part that does (measured: gfx950
+// checks the access, not its dwords) -- so a load that is not wholly inside is made again in four parts (neighbour byte,
+// two dwords, neighbour byte), each inside or outside as a whole: the rows above and below the image (all zero -- but for
+// the byte "left of" column 0 of row H, which is the image's last byte: what the naive filters' window at (H-1) * W
+// reaches), the first strip of row 0 (nothing to its left) and the last strip of row H-1 (nothing to its right).  One
+// compare and a branch few lanes take, where the flat loads had a branch per case and a clamp.
 template <bool NAIVE>
-__device__ __forceinline__ void pre_load_row(const uint8_t* __restrict__ raw, long n, int W, int H,
-                                             int r, int x0, PreRow& o) {
+__device__ __forceinline__ void pre_load_row(const __amdgpu_buffer_rsrc_t raw, uint32_t nbytes, int W, int r, int x0, PreRow& o) {
+  static_assert(PP_PX == 8, "16 bytes hold an 8-pixel strip and its neighbours");
   int p[PP_PX + 2];
-  // A row outside the image (above the first strip, below the last) reads as zeros.  It is fetched all the same, from the
-  // nearest row inside, and zeroed behind a branch only those strips take: with the zeros as the other arm of an if / else
-  // around the loads, every row of every strip began with ten v_mov of them.
-  const bool outside = r < 0 || r >= H;
-  {
-    const int rc = min(max(r, 0), H - 1);
-    const int k = rc * W + x0;  // (an image has at most 2^30 pixels, check_dims: 32-bit offsets inside it)
-    uint32_t w[PP_PX / 4];
-#if !defined(PP_NARROW_LOADS) && PP_PX == 8
-    if (k >= 4 && k + 12 <= (int)n) {
-      // ONE 16-byte load (4-byte aligned) brings the strip and both neighbours, bytes k-4 .. k+11, where the
-      // 8-byte load + two byte loads below issue three instructions (measured on one box: 172 -> 148 us per
-      // 256 pairs; only the image's first and last strip take the other path)
-      const uint4 v = *reinterpret_cast<const uint4*>(raw + k - 4);
-      w[0] = v.y; w[1] = v.z;
-      p[0] = (int)(v.x >> 24);
-      p[PP_PX + 1] = (int)(v.w & 0xFFu);
-    } else
-#endif
-    {
-    if (PP_PX == 16) {
-      const uint4 v = *reinterpret_cast<const uint4*>(raw + k);
-      w[0] = v.x; w[1] = v.y; w[PP_PX / 4 - 2] = v.z; w[PP_PX / 4 - 1] = v.w;
-    } else {
-      const uint2 v = *reinterpret_cast<const uint2*>(raw + k);
-      w[0] = v.x; w[1] = v.y;
-    }
-    p[0] = (k - 1 >= 0) ? raw[k - 1] : 0;
-    p[PP_PX + 1] = (k + PP_PX < (int)n) ? raw[k + PP_PX] : 0;
-    }
-    // (taking these two neighbour bytes from the adjacent lanes with wave_shr / wave_shl DPP moves instead, memory
-    // only at the wave's ends, measured SLOWER on the same box: 230 vs 191 us per 256 pairs)
-#pragma unroll
-    for (int i = 0; i < PP_PX; ++i) p[1 + i] = (w[i / 4] >> (8 * (i % 4))) & 0xFF;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t k = (uint32_t)(r * W + x0);
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(raw, k - 4u, 0, 0);
+  if (k - 4u > nbytes - 16u) {  // (unsigned: a negative offset is a huge one)
+    v.x = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(raw, k - 1u, 0, 0) << 24;
+    v.y = __builtin_amdgcn_raw_buffer_load_b32(raw, k, 0, 0);
+    v.z = __builtin_amdgcn_raw_buffer_load_b32(raw, k + 4u, 0, 0);
+    v.w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(raw, k + 8u, 0, 0);
   }
-  if (outside) {
+  p[0] = (int)(v.x >> 24);
+  p[PP_PX + 1] = (int)(v.w & 0xFFu);
+  // (taking these two neighbour bytes from the adjacent lanes with wave_shr / wave_shl DPP moves instead, memory
+  // only at the wave's ends, measured SLOWER on the same box: 230 vs 191 us per 256 pairs)
 #pragma unroll
-    for (int i = 0; i < PP_PX + 2; ++i) p[i] = 0;
-    // linear addressing: the byte "left of" column 0 of the row below the image is the image's
-    // last byte (the naive filters' window at position (H-1)*W reaches it)
-    if (r == H && x0 == 0) p[0] = raw[n - 1];
-  }
+  for (int i = 0; i < PP_PX; ++i) p[1 + i] = ((i < 4 ? v.y : v.z) >> (8 * (i % 4))) & 0xFF;
 #pragma unroll
   for (int i = 0; i < PP_PX; ++i) o.h[i] = NAIVE ? (p[i] + p[i + 1] + p[i + 2]) : third(p[i] + p[i + 1] + p[i + 2]);
 #pragma unroll
@@ -194,6 +175,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
   // columns 0, 1 and W-1 of smooth are cleared (buffer.hpp:637-652): only the image's first and last strip have a byte to
   // clear -- a branch those two lanes take (kept as masks the two words cost two registers the kernel does not have)
   const bool strip_first = x0 == 0, strip_last = x0 + PP_PX == W;
+  const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw), 0, (int)n, 0x00020000);
   PreRow rows[3];
 #if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
 #ifndef PP_DEPTH
@@ -206,8 +188,8 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
   pre_unpack_row<NAIVE>(rv[0], rows[0]);
   pre_unpack_row<NAIVE>(rv[1], rows[1]);
 #else
-  pre_load_row<NAIVE>(raw, n, W, H, ys - 1, x0, rows[0]);
-  pre_load_row<NAIVE>(raw, n, W, H, ys, x0, rows[1]);
+  pre_load_row<NAIVE>(rs_raw, (uint32_t)n, W, ys - 1, x0, rows[0]);
+  pre_load_row<NAIVE>(rs_raw, (uint32_t)n, W, ys, x0, rows[1]);
 #endif
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
@@ -222,7 +204,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
     asm volatile("" ::: "memory");  // (keeps the requests where they are: hoisted to the top they cost the kernel its occupancy)
     pre_unpack_row<NAIVE>(rv[i + 2], dn);
 #else
-    pre_load_row<NAIVE>(raw, n, W, H, y + 1, x0, dn);
+    pre_load_row<NAIVE>(rs_raw, (uint32_t)n, W, y + 1, x0, dn);
 #endif
 
     // ---- box + clearBoundary
