@@ -568,7 +568,7 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   // the 512 slots and split the tile rows evenly.  cost ~ rounds * tiles per workgroup.
   // tiles cover the candidate rows 13 .. H-14 only (k_hash.h)
   // the gradient image is k_preprocess's bit image: the batched SSE pipelines (run_preprocess(..., gradbits))
-  const bool gbits = c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive;
+  const bool gbits = c->grad_is_bits && d_grad == (const uint8_t*)c->grad.p && !dense && !c->naive && d_cand == nullptr;
   const int slots = 2 * (c->num_cus > 0 ? c->num_cus : 256);  // workgroups of k_hash the device holds at once (2 per CU: 67-76 KiB of LDS each)
   const int gx = (W + HT_X - 1) / HT_X;
   int ty = HT_Y;

@@ -332,7 +332,8 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   const uint8_t* sm = smooth + (long)img * n;
   static_assert(!GBITS || (!DENSE && !NAIVE), "the bit image exists in the batched SSE pipelines only");
   const uint8_t* gr = grad + (long)img * (GBITS ? n / 8 : n);
-  const uint8_t* cm = candmap ? candmap + (long)img * n : nullptr;
+  // (the bit image's launches never bring a candidate map -- run_hash: gbits requires d_cand == nullptr)
+  const uint8_t* cm = (!GBITS && candmap) ? candmap + (long)img * n : nullptr;
   uint32_t* out = codes + (long)img * n;
   const int tx0 = bx * HT_X;
   const int tid = threadIdx.x;
@@ -455,6 +456,21 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   uint32_t cand8[RPW];
   bool rowdo[RPW];
   bool any = false;
+  if (GBITS) {
+    // straight-line for the bit image: the fetched word is 0 for a row below the image and for a lane beyond its width
+    // (buffer loads), so what is left of the row conditions is "above the last 13 rows" for the candidates and "above
+    // the last 15" for the rows that are hashed -- two compares per row, no EXEC region
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int y = yw + r;
+      const uint32_t g4 = gq[r];
+      const uint32_t nib = (g4 >> (x0 & 15)) & 0xFu;
+      const uint32_t cb = (nib * 0x10204080u) & SW_H & xmask & (y < H - GPC_R ? ~0u : 0u);
+      cand8[r] = cb;
+      rowdo[r] = (y < H - 15) & (g4 != 0u);  // gpcFilterSegment(13, height-15) :602; groups without a gradient byte are skipped :566
+      any = any | ((cb != 0u) & rowdo[r]);
+    }
+  } else
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int y = yw + r;
