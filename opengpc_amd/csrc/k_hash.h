@@ -556,12 +556,25 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
     if ((x0 < W) && (y < H)) {
       uint4 o;
       uint32_t* op = reinterpret_cast<uint32_t*>(&o);
+      if (DENSE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t c = rowdo[r] ? code[r][j] : 0u;
-        cor |= c;
-        const bool is_cand = (cand8[r] >> (8 * j + 7)) & 1u;
-        op[j] = DENSE ? ((NAIVE && !is_cand) ? 0u : c) : (is_cand ? c : GPC_NOCAND);
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t c = rowdo[r] ? code[r][j] : 0u;
+          cor |= c;
+          const bool is_cand = (cand8[r] >> (8 * j + 7)) & 1u;
+          op[j] = (NAIVE && !is_cand) ? 0u : c;
+        }
+      } else {
+        // a candidate gets its code (0 where the row's 16-pixel group was skipped), anything else GPC_NOCAND (all ones):
+        // (code & do & cand) | ~cand with the candidate bit spread over the word by a signed bit-field extract -- one
+        // v_bfe_i32 + one v_bitop3 per pixel (select by select it was two v_cndmask, an and and a compare)
+        const uint32_t dom = rowdo[r] ? ~0u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t cm4 = (uint32_t)__builtin_amdgcn_sbfe((int)cand8[r], 8 * j + 7, 1);  // all ones for a candidate
+          cor |= code[r][j] & dom;
+          op[j] = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cm4, 0xD5);  // cand ? (code & do) : all ones
+        }
       }
 #if defined(HT_EXP_NOSTORE)   // experiment: how much of the kernel is the code image's write stream?
       if (o.x == 0x12345678u && W < 0) *reinterpret_cast<uint4*>(out + (uint32_t)(y * W + x0)) = o;
