@@ -499,11 +499,14 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 
   // ---- the tests, in the reference's byte planes: P0 = tests 0..7, (test 8), P1 = 9..16,
   //      P2 = 17..24, P3 = 25..31.  Tests >= T are padded with equal taps (compare false).
-  uint32_t code[RPW][4];
+  // The planes hold NOT(code bit).  The batched SSE instantiations keep the codes complemented through the transposes and
+  // take the complement inside the store phase's v_bitop3 (a truth table costs nothing): four v_not per row less.
+  constexpr bool INV = !DENSE && !NAIVE;
+  uint32_t code[RPW][4];   // INV: the complemented codes
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) code[r][j] = 0;
+    for (int j = 0; j < 4; ++j) code[r][j] = INV ? ~0u : 0u;
   HT_STAMP(3);   // candidate flags, group activity
 
 #ifdef HT_EXP_NOCOMPUTE
@@ -531,11 +534,13 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       // planes hold "b >= a"; the code bit is its complement.  P3 saw 7 tests: one more shift.
-      const uint32_t q0 = NAIVE ? ~p0[r] : (~p0[r] | ((~p8[r] >> 7) & m8));
-      const uint32_t q1 = ~p1[r];
-      const uint32_t q2 = ~p2[r];
+      // (INV: the same with every term complemented -- ~(~p0 | ((~p8 >> 7) & m8)) = p0 & ((p8 >> 7) | ~m8) on the bits m8
+      //  selects, ~((~p3 >> s) & m3) = (p3 >> s) | ~m3 on the bits m3 selects: neither shift crosses into a selected bit)
+      const uint32_t q0 = INV ? (p0[r] & ((p8[r] >> 7) | ~m8)) : (NAIVE ? ~p0[r] : (~p0[r] | ((~p8[r] >> 7) & m8)));
+      const uint32_t q1 = INV ? p1[r] : ~p1[r];
+      const uint32_t q2 = INV ? p2[r] : ~p2[r];
       // P3 saw n3 tests (first one now n3 - 1 places below bit 7): bring the first down to bit 0
-      const uint32_t q3 = NAIVE ? ~p3[r] : ((~p3[r] >> (8 - n3)) & m3);
+      const uint32_t q3 = INV ? ((p3[r] >> (8 - n3)) | ~m3) : (NAIVE ? ~p3[r] : ((~p3[r] >> (8 - n3)) & m3));
       // transpose 4 planes x 4 pixels -> 4 codes (byte k of code j = plane k, byte j)
       const uint32_t lo01 = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
       const uint32_t hi01 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
@@ -572,8 +577,13 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const uint32_t cm4 = (uint32_t)__builtin_amdgcn_sbfe((int)cand8[r], 8 * j + 7, 1);  // all ones for a candidate
-          cor |= code[r][j] & dom;
-          op[j] = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cm4, 0xD5);  // cand ? (code & do) : all ones
+          if (INV) {
+            cor = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cor, 0xAE);    // cor | (~ncode & do)
+            op[j] = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cm4, 0x5D);  // cand ? (~ncode & do) : all ones
+          } else {
+            cor |= code[r][j] & dom;
+            op[j] = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cm4, 0xD5);  // cand ? (code & do) : all ones
+          }
         }
       }
 #if defined(HT_EXP_NOSTORE)   // experiment: how much of the kernel is the code image's write stream?
