@@ -212,10 +212,24 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
 #pragma unroll
     for (int q = 0; q < PP_PX / 4; ++q) sw[q] = 0;
     if (y >= 1 && y <= box_last) {
+      if (!NAIVE) {
+        // third(s) = (s * 21846) >> 16 with s <= 765: the product is below 2^24, the quotient is its byte 2.  Four
+        // products become a word of four quotients with three byte permutes (shift, mask and OR per pixel were twelve).
+        uint32_t pr[PP_PX];
 #pragma unroll
-      for (int j = 0; j < PP_PX; ++j) {
-        const int v = NAIVE ? (up.h[j] + mid.h[j] + dn.h[j]) / 9 : third(up.h[j] + mid.h[j] + dn.h[j]);
-        sw[j / 4] |= (uint32_t)v << (8 * (j % 4));
+        for (int j = 0; j < PP_PX; ++j) pr[j] = __umul24((uint32_t)(up.h[j] + mid.h[j] + dn.h[j]), 21846u);
+#pragma unroll
+        for (int q = 0; q < PP_PX / 4; ++q) {
+          const uint32_t lo = __builtin_amdgcn_perm(pr[4 * q + 1], pr[4 * q], 0x0C0C0602u);      // [p0.b2, p1.b2, 0, 0]
+          const uint32_t hi = __builtin_amdgcn_perm(pr[4 * q + 3], pr[4 * q + 2], 0x06020C0Cu);  // [0, 0, p2.b2, p3.b2]
+          sw[q] = lo | hi;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PP_PX; ++j) {
+          const int v = (up.h[j] + mid.h[j] + dn.h[j]) / 9;
+          sw[j / 4] |= (uint32_t)v << (8 * (j % 4));
+        }
       }
       if (strip_first) sw[0] &= 0xFFFF0000u;               // columns 0 and 1
       if (strip_last) sw[PP_PX / 4 - 1] &= 0x00FFFFFFu;    // column W-1
