@@ -102,17 +102,21 @@ __device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
   return __builtin_amdgcn_perm(ro, re, 0x07030501u);  // high bytes back in place: [e.1, o.1, e.3, o.3]
 }
 
-// ~_mm_subs_epi8(b, tau): the bytewise complement of the saturated difference, for -127 <= tau <= 127.  ~s = -s - 1 maps
-// [-128, 127] onto itself in reverse order, so ~clamp(s - tau) = clamp((tau - 1) - s): the same two packed subtracts with
-// the constant as the minuend.  Lane arithmetic: ((tau - 1) * 256 + 255) - (s * 256 + g) = (tau - 1 - s) * 256 + (255 - g),
-// 0 <= 255 - g <= 255: the high-byte argument of subs_epi8x4 again.  tau_rev = that minuend in both 16-bit halves
-// (tau = -128 has no such minuend in 16 bits: the caller complements subs_epi8x4's result instead).
-__device__ __forceinline__ uint32_t subs_epi8x4_not(uint32_t b, uint32_t tau_rev) {
-  const uint32_t xe = b << 8;
+// ~_mm_subs_epi8(b, tau): the bytewise complement of the saturated difference, for EVERY tau.  ~s = -s - 1 maps [-128, 127]
+// onto itself in reverse order, so ~clamp(s - tau) = clamp((tau - 1) - s): the same two packed subtracts with the constant as
+// the minuend.  The byte below the int8 in its 16-bit lane is forced to 255 first (one OR; for the even bytes it rides in
+// the shift: v_lshl_or_b32), the minuend is tau * 256: (tau * 256) - (s * 256 + 255) = (tau - 1 - s) * 256 + 1 leaves
+// [-32768, 32767] exactly when tau - 1 - s leaves [-128, 127], and a saturated lane has the saturated int8 in its high
+// byte.  tau_hi = (tau & 0xFF) << 8 in both halves -- the constant of subs_epi8x4 itself, -128 included (with the low byte
+// left as it lies the minuend would be (tau - 1) * 256 + 255, which -128 does not have in 16 bits: that cost every test
+// of the kernel a three-way branch, ~20 scalar instructions).
+__device__ __forceinline__ uint32_t subs_epi8x4_not(uint32_t b, uint32_t tau_hi) {
+  const uint32_t xe = (b << 8) | 0x00FF00FFu;  // lanes [b0 : 255], [b2 : 255]
+  const uint32_t xo = b | 0x00FF00FFu;         // lanes [b1 : 255], [b3 : 255]
   gpc_short2 t, e, o;
-  __builtin_memcpy(&t, &tau_rev, 4);
+  __builtin_memcpy(&t, &tau_hi, 4);
   __builtin_memcpy(&e, &xe, 4);
-  __builtin_memcpy(&o, &b, 4);
+  __builtin_memcpy(&o, &xo, 4);
   e = __builtin_elementwise_sub_sat(t, e);
   o = __builtin_elementwise_sub_sat(t, o);
   uint32_t re, ro;
@@ -236,17 +240,12 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
         // The compare needs one operand complemented: here the saturating subtract delivers ~b' itself (no v_not),
         // v_lerp_u8(a, ~b', 0) has bit 7 = (a + 255 - b' >= 256) = (a > b') = the code bit, and the plane takes its
         // complement (the planes hold NOT(code bit), complemented once per row at the end).
-        if (tau != 0x80) {
-          const uint32_t tau_rev = ((uint32_t)((tau - 1) & 0xFF) * 0x01000100u) | 0x00FF00FFu;
+        {
+          const uint32_t tau_hi = (uint32_t)tau * 0x01000100u;
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
-            plane[r] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_rev), 0u),
+            plane[r] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_hi), 0u),
                                                    plane[r] >> 1, SW_H, 0x4E);
-        } else {
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            plane[r] = __builtin_amdgcn_bitop3_b32(swar_ge(a[i % D][r], subs_epi8x4(b[i % D][r], 0x80008000u)), plane[r] >> 1,
-                                                   SW_H, 0xE4);
         }
       } else {
 #pragma unroll

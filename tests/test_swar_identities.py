@@ -28,12 +28,23 @@ def test_saturating_subtract_in_the_high_byte_ignores_the_low_byte():
 
 
 def test_complemented_saturating_subtract_with_the_constant_as_minuend():
-    """subs_epi8x4_not: ~clamp(s - tau) = high byte of sat16(((tau - 1) * 256 + 255) - lane) for -127 <= tau <= 127."""
+    """~clamp(s - tau) = high byte of sat16(((tau - 1) * 256 + 255) - lane) for -127 <= tau <= 127, whatever the low byte (the
+    form k_hash used first: tau = -128 has no such minuend in 16 bits)."""
     for tau in range(-127, 128):
         want = ~np.clip(S - tau, -128, 127) + 0 * G
         minuend = (tau - 1) * 256 + 255
         assert -32768 <= minuend <= 32767
         got = high_byte(sat16(minuend - lanes(S, G)))
+        assert np.array_equal(got, want), tau
+
+
+def test_complemented_saturating_subtract_every_tau_with_the_low_byte_forced():
+    """subs_epi8x4_not: with the byte below the int8 forced to 255, ~clamp(s - tau) = high byte of sat16(tau * 256 - lane) for
+    EVERY tau in int8 -- the minuend is subs_epi8x4's own constant."""
+    for tau in range(-128, 128):
+        want = ~np.clip(S - tau, -128, 127)
+        assert -32768 <= tau * 256 <= 32767
+        got = high_byte(sat16(tau * 256 - lanes(S, np.full_like(S, 255))))
         assert np.array_equal(got, want), tau
 
 
