@@ -5,7 +5,8 @@
 // (:41-50), Buffer<T> (:142-193: row-major, columns padded to a multiple of 16, public
 // width/height), clearBoundary (:630-654), PNG read/write (:197-474) and the KITTI-colour
 // disparity overlay (:949-1014).  Same names, argument meaning and error behaviour
-// (messages on stdout, sentinel return values); storage is a plain zero-initialised vector.
+// (messages on stdout, sentinel return values); storage is a vector, zero-initialised by the public constructors (the
+// reference's Eigen arrays are not initialised at all; Buffer::uninitialized gives the library's own outputs the same).
 #ifndef GPC_AMD_NDB_BUFFER_HPP
 #define GPC_AMD_NDB_BUFFER_HPP
 
@@ -13,7 +14,10 @@
 #include <cstdint>
 #include <cstring>
 #include <iostream>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gpc/png_io.hpp"
@@ -70,6 +74,29 @@ struct Dimension {
 
 inline int align16(int x) { return (x % 16) == 0 ? x : ((x / 16) + 1) * 16; }
 
+namespace detail {
+// std::allocator whose value-less construct() default-initialises: resize(n) of a vector of bytes touches no memory, so an
+// image the device is about to fill is written once, not twice
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef default_init_allocator<U> other;
+  };
+  default_init_allocator() {}
+  template <class U>
+  default_init_allocator(const default_init_allocator<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+  }
+};
+}  // namespace detail
+
 template <class T>
 class Buffer {
  public:
@@ -77,8 +104,19 @@ class Buffer {
   int height = 0;  // visible height (== rows())
 
   Buffer() {}
-  Buffer(int r, int c) : width(c), height(r), rows_(r), cols_(align16(c)), v_((size_t)r * align16(c)) {}
+  Buffer(int r, int c) : width(c), height(r), rows_(r), cols_(align16(c)), v_((size_t)r * align16(c), T()) {}
   Buffer(int r, int c, T color) : width(c), height(r), rows_(r), cols_(align16(c)), v_((size_t)r * align16(c), color) {}
+
+  // contents unspecified, as the reference's Buffer(r, c) leaves them (buffer.hpp:145: an Eigen array)
+  static Buffer uninitialized(int r, int c) {
+    Buffer b;
+    b.width = c;
+    b.height = r;
+    b.rows_ = r;
+    b.cols_ = align16(c);
+    b.v_.resize((size_t)r * align16(c));
+    return b;
+  }
 
   int rows() const { return rows_; }
   int cols() const { return cols_; }
@@ -94,7 +132,7 @@ class Buffer {
   }
   // keeps the top-left block
   void conservativeResize(int r, int c) {
-    std::vector<T> n((size_t)r * c, T());
+    std::vector<T, detail::default_init_allocator<T>> n((size_t)r * c, T());
     const int rr = std::min(r, rows_), cc = std::min(c, cols_);
     for (int y = 0; y < rr; ++y)
       for (int x = 0; x < cc; ++x) n[(size_t)y * c + x] = v_[(size_t)y * cols_ + x];
@@ -202,7 +240,7 @@ class Buffer {
 
  private:
   int rows_ = 0, cols_ = 0;
-  std::vector<T> v_;
+  std::vector<T, detail::default_init_allocator<T>> v_;
 };
 
 template <class T>

@@ -96,6 +96,14 @@ int gpc_hip_synchronize(gpc_hip_ctx* ctx);
  * entry points below grow them on demand, which costs a hipMalloc + sync). */
 int gpc_hip_reserve(gpc_hip_ctx* ctx, int width, int height, int max_pairs);
 
+/* Pays, outside the caller's timed region, for everything a first call would otherwise pay inside it: the library's code
+ * objects, the workspaces of one pair of width x height, page-locked staging, streams and worker threads.  The reference's
+ * sample starts its clock after Forest::readForest(path, width, height) (samples/sparsematch.cpp:42-45) -- the one call
+ * that knows the image size -- so the C++ API calls this from there; a C caller does it after gpc_hip_set_forest (the
+ * forest must be set: GPC_E_NO_FOREST otherwise).  Runs the host entry points once on a synthetic pair and discards the
+ * results.  settings == NULL: all four matcher modes (epipolar x hashtable). */
+int gpc_hip_warmup(gpc_hip_ctx* ctx, int width, int height, const gpc_settings* settings);
+
 /* The reference has two arithmetic variants chosen at BUILD time (samples/CMakeLists.txt:13-20):
  * SSE=ON (-D_INTRINSICS_SSE, the default and the parity target of this library) and SSE=OFF
  * (boxNaive / sobelNaive / gpcFilter(Tau)Naive, filter.hpp:157-282), which produce different
@@ -126,6 +134,26 @@ int gpc_hip_set_forest(gpc_hip_ctx* ctx, const gpc_filter_mask* fm);
 int gpc_hip_preprocess(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height,
                        int gradient_threshold, uint8_t* smooth, uint8_t* grad,
                        int32_t* mask, int mask_cap, int* n_mask);
+/* The same in two steps, for callers that size their arrays by the candidate count (std::vector<int> mask of
+ * Forest::PreprocessedImage, inference.hpp:161-165): _begin runs the kernels, leaves the three results in page-locked
+ * staging memory of the context and returns the count; _fetch copies them into the caller's arrays (any may be NULL;
+ * GPC_E_CAPACITY if mask_cap is short, the first mask_cap indices are delivered).  Exactly one _fetch per _begin, no
+ * other call on the context in between.
+ *
+ * Resident images.  The image also STAYS on the device (the last two per context), and the arrays handed to _fetch (or to
+ * gpc_hip_preprocess) are remembered as its host copies.  gpc_hip_rectified_match / gpc_hip_stereo_match recognise them --
+ * same addresses, same sizes, same arithmetic mode, and a fingerprint of their contents (64 words spread over each array)
+ * unchanged -- and then hash and match from the device copies instead of uploading smooth, grad and mask again: the
+ * reference's by-value PreprocessedImage without its round trip over the link.  Anything else (copies of the arrays,
+ * edited arrays, arrays from another context) takes the upload path; the results are the same either way.  A caller that
+ * EDITS a delivered array in place in a way 64 samples can miss must set GPC_HIP_RESIDENT=2 (every byte is hashed) or
+ * GPC_HIP_RESIDENT=0 (never resident).  Every library call that writes over a remembered array forgets it. */
+int gpc_hip_preprocess_begin(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height,
+                             int gradient_threshold, int* n_mask);
+int gpc_hip_preprocess_fetch(gpc_hip_ctx* ctx, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap);
+/* Match calls of this context served from resident images so far (tests, diagnostics). */
+int gpc_hip_resident_hits(const gpc_hip_ctx* ctx);
+
 /* ndb::gpcFilter / gpcFilterTau as called by evalFastMaskOnSubsetSSE
  * (inference.hpp:266-292): dense code image, width*height uint32, zero where the
  * reference leaves its zero-filled buffer untouched. */

@@ -71,7 +71,8 @@ SYMBOLS = [
     "gpc_hip_abi_version", "gpc_hip_status_string", "gpc_hip_device_count", "gpc_hip_create",
     "gpc_hip_destroy", "gpc_hip_last_error", "gpc_hip_set_stream", "gpc_hip_synchronize",
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
-    "gpc_hip_preprocess", "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
+    "gpc_hip_warmup", "gpc_hip_preprocess", "gpc_hip_preprocess_begin", "gpc_hip_preprocess_fetch", "gpc_hip_resident_hits",
+    "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
@@ -111,6 +112,10 @@ def load():
     L.gpc_hip_set_forest.argtypes = [C.c_void_p, C.POINTER(FilterMask)]
     L.gpc_hip_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.gpc_hip_warmup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Settings)]
+    L.gpc_hip_preprocess_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.gpc_hip_preprocess_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.gpc_hip_resident_hits.argtypes = [C.c_void_p]
     L.gpc_hip_hash_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     pre = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
            C.c_int, C.c_int, C.c_int, C.POINTER(Settings), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -289,6 +294,27 @@ class Context:
         self._ck(self.L.gpc_hip_preprocess(self.h, _ptr(raw), W, H, int(threshold), _ptr(smooth), _ptr(grad),
                                            _ptr(mask), mask.size, C.byref(n)))
         return smooth, grad, mask[:n.value].copy()
+
+    def preprocess_resident(self, raw, threshold):
+        """gpc_hip_preprocess_begin + _fetch: the arrays returned are the ones the library filled and remembers as the
+        host copies of the image it keeps on the device -- hand THEM (not copies) to rectified_match / stereo_match and
+        the match runs from the resident image (resident_hits() counts those calls)."""
+        raw = np.ascontiguousarray(raw, np.uint8)
+        H, W = raw.shape
+        n = C.c_int()
+        self._ck(self.L.gpc_hip_preprocess_begin(self.h, _ptr(raw), W, H, int(threshold), C.byref(n)))
+        smooth = np.empty((H, W), np.uint8)
+        grad = np.empty((H, W), np.uint8)
+        mask = np.empty(n.value, np.int32)
+        self._ck(self.L.gpc_hip_preprocess_fetch(self.h, _ptr(smooth), _ptr(grad), _ptr(mask), mask.size))
+        return smooth, grad, mask
+
+    def resident_hits(self):
+        return self.L.gpc_hip_resident_hits(self.h)
+
+    def warmup(self, width, height, settings=None):
+        """gpc_hip_warmup: first-use costs of a pair of this size, paid now (the forest must be set)."""
+        self._ck(self.L.gpc_hip_warmup(self.h, width, height, C.byref(settings) if settings is not None else None))
 
     def hash_codes(self, smooth, grad):
         smooth = np.ascontiguousarray(smooth, np.uint8)

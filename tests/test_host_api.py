@@ -234,6 +234,28 @@ def test_reference_sample_runs_on_the_hip_path(tmp_path, golden, forest_paths):
     assert os.path.exists(str(tmp_path / "disparity.png"))
 
 
+TIMES = re.compile(r"tPreprocess: ([\d.e+-]+) ms.*tMatch: ([\d.e+-]+) ms")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_ON_AMD), reason="reference sample build not present")
+def test_reference_sample_one_shot_is_fast(tmp_path, golden, forest_paths):
+    """BASELINE configs[0]/[1] literally: the reference's unchanged sample, ONE process, ONE pair.  Its clock starts after
+    readForest (samples/sparsematch.cpp:42-45), which is where this build makes the device context, loads the code
+    objects and reserves the workspaces -- so the printed tPreprocess + tMatch is the work, not the start-up
+    (round 4 printed 222 + 20 ms here; the CPU reference prints 9.5 + 35 ms)."""
+    c = golden["cases"][1]
+    L, R, lp, rp = write_pair(tmp_path, c["W"], c["H"], c["s"], c["D"])
+    sums = []
+    for _ in range(3):                 # three fresh processes; the median is asserted (a shared box can hiccup once)
+        out = run(REF_ON_AMD, forest_paths["zero"], lp, rp, cwd=str(tmp_path))
+        m, t = LINE.search(out), TIMES.search(out)
+        assert m and t, out
+        assert [int(m.group(1)), int(m.group(2)), int(m.group(3))] == c["n_cand"] + [c["zero"]["epipolar"]["n"]]
+        sums.append(float(t.group(1)) + float(t.group(2)))
+    assert sorted(sums)[1] < 5.0, sums
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("epipolar,hashtable", [(1, 0), (0, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize("sse", [True, False], ids=["sse_build", "naive_build"])
