@@ -93,24 +93,7 @@ struct ContextHolder {
   size_t support_hint = 0;  // supports of this thread's last matchPair call (+ slack): how large the next result array starts
   gpc_filter_mask warmed;   // the forest (with its image size) readForest last warmed this thread's context for
   bool have_warmed = false;
-  // matchPair's page-locked staging: the two images go in and the supports come out through memory the device reads and
-  // writes directly (ndb::Buffer and std::vector are pageable: the runtime would stage every copy itself, synchronously)
-  void* pin_in = nullptr;
-  void* pin_out = nullptr;
-  size_t pin_in_cap = 0, pin_out_cap = 0;
-  bool pinned(void** p, size_t* cap, size_t bytes) {
-    if (bytes <= *cap) return true;
-    if (*p) gpc_hip_host_free(ctx, *p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = bytes + bytes / 4;
-    if (gpc_hip_host_alloc(ctx, want, p) != GPC_OK) return false;
-    *cap = want;
-    return true;
-  }
   ~ContextHolder() {
-    if (ctx && pin_in) gpc_hip_host_free(ctx, pin_in);
-    if (ctx && pin_out) gpc_hip_host_free(ctx, pin_out);
     if (ctx) gpc_hip_destroy(ctx);
   }
 };
@@ -252,24 +235,27 @@ class Forest {
            "gradientThreshold needs to be within 0...255");
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx) return PreprocessedImage();
-    int n = 0;
-    int st = gpc_hip_preprocess_begin(h.ctx, img.data(), img.cols(), img.rows(), settings.gradientThreshold_, &n);
+    int st = gpc_hip_preprocess_begin(h.ctx, img.data(), img.cols(), img.rows(), settings.gradientThreshold_);
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_preprocess");
       return PreprocessedImage();
     }
-    // the arrays the caller keeps are written once, by the library (no zero fill first, no copy of a copy)
+    // The arrays the caller keeps are made WHILE the device works, and written once, by the library's threads (no copy
+    // of a copy).  The candidate list is sized for every pixel inside the margin and cut to the count afterwards.
     PreprocessedImage r;
     r.smooth = ndb::Buffer<uint8_t>::uninitialized(img.rows(), img.cols());
     r.smooth.width = img.width;
     r.grad = ndb::Buffer<uint8_t>::uninitialized(img.rows(), img.cols());
     r.grad.width = img.width;
-    r.mask.resize((size_t)n);
-    st = gpc_hip_preprocess_fetch(h.ctx, r.smooth.data(), r.grad.data(), r.mask.data(), n);
+    const size_t maxcand = (size_t)(img.cols() - 2 * GPC_PATCH_RADIUS) * (size_t)(img.rows() - 2 * GPC_PATCH_RADIUS);
+    r.mask.resize(maxcand);
+    int n = 0;
+    st = gpc_hip_preprocess_fetch(h.ctx, r.smooth.data(), r.grad.data(), r.mask.data(), (int)maxcand, &n);
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_preprocess");
       return PreprocessedImage();
     }
+    r.mask.resize((size_t)n);
     return r;
   }
 
@@ -283,24 +269,23 @@ class Forest {
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Correspondence>();
     const gpc_settings s = settings.toC();
-    // the results land in page-locked memory of this thread's context (the join writes them there over the link) and
-    // become the vector in one pass
-    const size_t cap = std::min(simg.mask.size(), timg.mask.size()) + 1;
-    if (!h.pinned(&h.pin_out, &h.pin_out_cap, cap * sizeof(gpc_correspondence))) {
-      detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
-      return std::vector<ndb::Correspondence>();
-    }
-    int n = 0;
-    const int st = gpc_hip_stereo_match(
+    // the kernels are queued, the result array is made (and zeroed by the allocator) while they run, the library's threads
+    // fill it; no match of two candidate lists has more results than the shorter list
+    int st = gpc_hip_stereo_match_begin(
         h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
-        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
-        static_cast<gpc_correspondence*>(h.pin_out), (int)cap, &n);
+        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s);
+    std::vector<ndb::Correspondence> corr;
+    int n = 0;
+    if (st == GPC_OK) {
+      corr.resize(std::min(simg.mask.size(), timg.mask.size()) + 1);
+      st = gpc_hip_match_fetch(h.ctx, corr.data(), (int)corr.size(), &n, nullptr, nullptr);
+    }
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_stereo_match");
       return std::vector<ndb::Correspondence>();
     }
-    const ndb::Correspondence* res = static_cast<const ndb::Correspondence*>(h.pin_out);
-    return std::vector<ndb::Correspondence>(res, res + n);
+    corr.resize((size_t)n);
+    return corr;
   }
 
   // inference.hpp:375-393
@@ -311,22 +296,21 @@ class Forest {
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
-    const size_t cap = std::min(simg.mask.size(), timg.mask.size()) + 1;  // (page-locked staging: see stereoMatch)
-    if (!h.pinned(&h.pin_out, &h.pin_out_cap, cap * sizeof(gpc_support))) {
-      detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
-      return std::vector<ndb::Support>();
-    }
-    int n = 0;
-    const int st = gpc_hip_rectified_match(
+    int st = gpc_hip_rectified_match_begin(   // (queued; the array is made while the kernels run: see stereoMatch)
         h.ctx, simg.smooth.data(), simg.grad.data(), simg.mask.data(), (int)simg.mask.size(), timg.smooth.data(),
-        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s,
-        static_cast<gpc_support*>(h.pin_out), (int)cap, &n);
+        timg.grad.data(), timg.mask.data(), (int)timg.mask.size(), simg.smooth.cols(), simg.smooth.rows(), &s);
+    std::vector<ndb::Support> supp;
+    int n = 0;
+    if (st == GPC_OK) {
+      supp.resize(std::min(simg.mask.size(), timg.mask.size()) + 1);
+      st = gpc_hip_match_fetch(h.ctx, supp.data(), (int)supp.size(), &n, nullptr, nullptr);
+    }
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_rectified_match");
       return std::vector<ndb::Support>();
     }
-    const ndb::Support* res = static_cast<const ndb::Support*>(h.pin_out);
-    return std::vector<ndb::Support>(res, res + n);
+    supp.resize((size_t)n);
+    return supp;
   }
 
   // Extension: preprocessImage x2 + rectifiedMatch without bringing the intermediates back
@@ -339,42 +323,30 @@ class Forest {
     detail::ContextHolder& h = detail::holder();
     if (!h.ctx || !upload(h, forestmask)) return std::vector<ndb::Support>();
     const gpc_settings s = settings.toC();
-    // Images and supports pass through page-locked staging memory of this thread's context (one memcpy each way on the
-    // host; the kernels read the images and write the 12-byte supports over the link themselves: the single-pair path of
-    // gpc_hip_match_batch).  The staging array is sized by the last call's count rather than by the worst case (one
-    // support per pixel), and never so small that a textured pair needs the call twice (the second attempt below).
-    const size_t npix = (size_t)simg.rows() * simg.cols();
-    size_t cap0 = h.support_hint ? h.support_hint : npix * 3 / 4 + 1;
-    if (cap0 > npix + 1) cap0 = npix + 1;
-    const size_t in_bytes = (npix + 15) / 16 * 16;  // the second image starts 16-byte aligned
-    if (!h.pinned(&h.pin_in, &h.pin_in_cap, 2 * in_bytes) || !h.pinned(&h.pin_out, &h.pin_out_cap, cap0 * sizeof(gpc_support))) {
-      detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
-      return std::vector<ndb::Support>();
-    }
-    uint8_t* pl = static_cast<uint8_t*>(h.pin_in);
-    uint8_t* pr = pl + in_bytes;
-    memcpy(pl, simg.data(), npix);
-    memcpy(pr, timg.data(), npix);
-    int n = 0;
-    int st = gpc_hip_match_pair(h.ctx, pl, pr, simg.cols(), simg.rows(), &s, static_cast<gpc_support*>(h.pin_out), (int)cap0, &n,
-                                candidatesL, candidatesR);
-    if (st == GPC_E_CAPACITY) {
-      cap0 = (size_t)n + 1;
-      if (!h.pinned(&h.pin_out, &h.pin_out_cap, cap0 * sizeof(gpc_support))) {
-        detail::fail(GPC_E_HIP, h.ctx, "gpc_hip_host_alloc");
-        return std::vector<ndb::Support>();
+    // Queued (the images pass through page-locked memory of the context); the result array is made while the kernels run,
+    // sized by this thread's last call rather than by the worst case (one support per pixel), and the library's threads
+    // fill it.  Results that do not fit are fetched again into a larger array (they stay with the context until its next call).
+    int st = gpc_hip_match_pair_begin(h.ctx, simg.data(), timg.data(), simg.cols(), simg.rows(), &s);
+    std::vector<ndb::Support> supp;
+    int n = 0, cl = 0, cr = 0;
+    if (st == GPC_OK) {
+      const size_t npix = (size_t)simg.rows() * simg.cols();
+      size_t cap0 = h.support_hint ? h.support_hint : npix * 3 / 4 + 1;
+      if (cap0 > npix + 1) cap0 = npix + 1;
+      supp.resize(cap0);
+      st = gpc_hip_match_fetch(h.ctx, supp.data(), (int)supp.size(), &n, &cl, &cr);
+      if (st == GPC_E_CAPACITY) {
+        supp.resize((size_t)n);
+        st = gpc_hip_match_fetch(h.ctx, supp.data(), (int)supp.size(), &n, &cl, &cr);
       }
-      st = gpc_hip_match_pair(h.ctx, pl, pr, simg.cols(), simg.rows(), &s, static_cast<gpc_support*>(h.pin_out), (int)cap0, &n,
-                              candidatesL, candidatesR);
     }
     if (st != GPC_OK) {
       detail::fail(st, h.ctx, "gpc_hip_match_pair");
-      if (candidatesL) *candidatesL = 0;
-      if (candidatesR) *candidatesR = 0;
       return std::vector<ndb::Support>();
     }
-    const ndb::Support* res = static_cast<const ndb::Support*>(h.pin_out);
-    std::vector<ndb::Support> supp(res, res + n);  // (one copy; no element-by-element value-initialisation first)
+    supp.resize((size_t)n);
+    if (candidatesL) *candidatesL = cl;
+    if (candidatesR) *candidatesR = cr;
     h.support_hint = (size_t)n + (size_t)n / 8 + 1024;
     return supp;
   }

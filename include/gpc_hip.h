@@ -134,23 +134,23 @@ int gpc_hip_set_forest(gpc_hip_ctx* ctx, const gpc_filter_mask* fm);
 int gpc_hip_preprocess(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height,
                        int gradient_threshold, uint8_t* smooth, uint8_t* grad,
                        int32_t* mask, int mask_cap, int* n_mask);
-/* The same in two steps, for callers that size their arrays by the candidate count (std::vector<int> mask of
- * Forest::PreprocessedImage, inference.hpp:161-165): _begin runs the kernels, leaves the three results in page-locked
- * staging memory of the context and returns the count; _fetch copies them into the caller's arrays (any may be NULL;
- * GPC_E_CAPACITY if mask_cap is short, the first mask_cap indices are delivered).  Exactly one _fetch per _begin, no
- * other call on the context in between.
+/* The same in two steps, so that the caller can allocate while the device works (the by-value PreprocessedImage of
+ * Forest::preprocessImage, inference.hpp:161-165, 302-333): _begin QUEUES the kernels -- the device writes smooth, grad and
+ * the candidate list into page-locked staging memory of the context over the link -- and returns; _fetch waits, copies the
+ * three results into the caller's arrays with the library's worker threads (any may be NULL; the candidate count is
+ * returned; GPC_E_CAPACITY if mask_cap is short, the first mask_cap indices are delivered).  An image has at most
+ * (width - 26) * (height - 26) candidates.  Exactly one _fetch per _begin, no other call on the context in between.
  *
  * Resident images.  The image also STAYS on the device (the last two per context), and the arrays handed to _fetch (or to
  * gpc_hip_preprocess) are remembered as its host copies.  gpc_hip_rectified_match / gpc_hip_stereo_match recognise them --
- * same addresses, same sizes, same arithmetic mode, and a fingerprint of their contents (64 words spread over each array)
+ * same addresses, same sizes, same arithmetic mode, and a fingerprint of their contents (66 words spread over each array)
  * unchanged -- and then hash and match from the device copies instead of uploading smooth, grad and mask again: the
  * reference's by-value PreprocessedImage without its round trip over the link.  Anything else (copies of the arrays,
  * edited arrays, arrays from another context) takes the upload path; the results are the same either way.  A caller that
- * EDITS a delivered array in place in a way 64 samples can miss must set GPC_HIP_RESIDENT=2 (every byte is hashed) or
+ * EDITS a delivered array in place in a way 66 samples can miss must set GPC_HIP_RESIDENT=2 (every byte is hashed) or
  * GPC_HIP_RESIDENT=0 (never resident).  Every library call that writes over a remembered array forgets it. */
-int gpc_hip_preprocess_begin(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height,
-                             int gradient_threshold, int* n_mask);
-int gpc_hip_preprocess_fetch(gpc_hip_ctx* ctx, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap);
+int gpc_hip_preprocess_begin(gpc_hip_ctx* ctx, const uint8_t* raw, int width, int height, int gradient_threshold);
+int gpc_hip_preprocess_fetch(gpc_hip_ctx* ctx, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap, int* n_mask);
 /* Match calls of this context served from resident images so far (tests, diagnostics). */
 int gpc_hip_resident_hits(const gpc_hip_ctx* ctx);
 
@@ -177,6 +177,25 @@ int gpc_hip_stereo_match(gpc_hip_ctx* ctx, const uint8_t* smoothL, const uint8_t
 int gpc_hip_match_pair(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
                        int width, int height, const gpc_settings* settings,
                        gpc_support* out, int cap, int* n_out, int* n_cand_l, int* n_cand_r);
+
+/* The three calls above in two steps each: *_begin queues the work and returns (the results go to page-locked memory of
+ * the context), gpc_hip_match_fetch waits and copies min(count, cap) records into `out` (gpc_support for the rectified and
+ * pair forms, gpc_correspondence for the stereo form) with the library's worker threads; *n_out is the true count
+ * (GPC_E_CAPACITY when it exceeds cap: fetch again with a larger array -- the results stay until the next call on the
+ * context).  n_cand_l / n_cand_r are filled after gpc_hip_match_pair_begin only.  Between the two steps the caller can
+ * allocate (and let the allocator zero) the array the results go to: that is what a std::vector<ndb::Support> of the
+ * reference's API costs, and here it runs beside the kernels instead of after them. */
+int gpc_hip_rectified_match_begin(gpc_hip_ctx* ctx, const uint8_t* smoothL, const uint8_t* gradL,
+                                  const int32_t* maskL, int n_maskL, const uint8_t* smoothR,
+                                  const uint8_t* gradR, const int32_t* maskR, int n_maskR,
+                                  int width, int height, const gpc_settings* settings);
+int gpc_hip_stereo_match_begin(gpc_hip_ctx* ctx, const uint8_t* smoothL, const uint8_t* gradL,
+                               const int32_t* maskL, int n_maskL, const uint8_t* smoothR,
+                               const uint8_t* gradR, const int32_t* maskR, int n_maskR,
+                               int width, int height, const gpc_settings* settings);
+int gpc_hip_match_pair_begin(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR,
+                             int width, int height, const gpc_settings* settings);
+int gpc_hip_match_fetch(gpc_hip_ctx* ctx, void* out, int cap, int* n_out, int* n_cand_l, int* n_cand_r);
 
 /* ---- device-resident batch entry points ------------------------------------- */
 /* `npairs` raw pairs already in HBM ([npairs][height][width] each side) -> supports in

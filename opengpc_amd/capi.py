@@ -72,6 +72,7 @@ SYMBOLS = [
     "gpc_hip_destroy", "gpc_hip_last_error", "gpc_hip_set_stream", "gpc_hip_synchronize",
     "gpc_hip_reserve", "gpc_hip_set_arithmetic", "gpc_hip_host_alloc", "gpc_hip_host_free", "gpc_hip_read_forest", "gpc_hip_parse_forest", "gpc_hip_set_forest",
     "gpc_hip_warmup", "gpc_hip_preprocess", "gpc_hip_preprocess_begin", "gpc_hip_preprocess_fetch", "gpc_hip_resident_hits",
+    "gpc_hip_rectified_match_begin", "gpc_hip_stereo_match_begin", "gpc_hip_match_pair_begin", "gpc_hip_match_fetch",
     "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
     "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
@@ -113,14 +114,19 @@ def load():
     L.gpc_hip_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.gpc_hip_warmup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Settings)]
-    L.gpc_hip_preprocess_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
-    L.gpc_hip_preprocess_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.gpc_hip_preprocess_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.gpc_hip_preprocess_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.gpc_hip_resident_hits.argtypes = [C.c_void_p]
     L.gpc_hip_hash_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     pre = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
            C.c_int, C.c_int, C.c_int, C.POINTER(Settings), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.gpc_hip_rectified_match.argtypes = pre
     L.gpc_hip_stereo_match.argtypes = pre
+    L.gpc_hip_rectified_match_begin.argtypes = pre[:12]
+    L.gpc_hip_stereo_match_begin.argtypes = pre[:12]
+    L.gpc_hip_match_pair_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Settings)]
+    L.gpc_hip_match_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
     L.gpc_hip_match_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(Settings), C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -301,13 +307,39 @@ class Context:
         the match runs from the resident image (resident_hits() counts those calls)."""
         raw = np.ascontiguousarray(raw, np.uint8)
         H, W = raw.shape
-        n = C.c_int()
-        self._ck(self.L.gpc_hip_preprocess_begin(self.h, _ptr(raw), W, H, int(threshold), C.byref(n)))
+        self._ck(self.L.gpc_hip_preprocess_begin(self.h, _ptr(raw), W, H, int(threshold)))
         smooth = np.empty((H, W), np.uint8)
         grad = np.empty((H, W), np.uint8)
-        mask = np.empty(n.value, np.int32)
-        self._ck(self.L.gpc_hip_preprocess_fetch(self.h, _ptr(smooth), _ptr(grad), _ptr(mask), mask.size))
-        return smooth, grad, mask
+        full = np.empty((W - 26) * (H - 26), np.int32)    # (allocated while the device works)
+        n = C.c_int()
+        self._ck(self.L.gpc_hip_preprocess_fetch(self.h, _ptr(smooth), _ptr(grad), _ptr(full), full.size, C.byref(n)))
+        return smooth, grad, full[:n.value]      # a view: the same address the library remembers
+
+    def match_async(self, kind, a, b, settings, cap=None):
+        """The two-step forms: kind 'rectified' / 'stereo' on (smooth, grad, mask) triples, 'pair' on raw images.
+        Returns (records, true count, status, (candidates L, candidates R) or None)."""
+        s_ = settings
+        if kind == "pair":
+            a = np.ascontiguousarray(a, np.uint8)
+            b = np.ascontiguousarray(b, np.uint8)
+            H, W = a.shape
+            self._ck(self.L.gpc_hip_match_pair_begin(self.h, _ptr(a), _ptr(b), W, H, C.byref(s_)))
+            dtype = SUPPORT_DTYPE
+        else:
+            (sl, gl, ml), (sr, gr, mr) = a, b
+            H, W = sl.shape
+            fn = self.L.gpc_hip_rectified_match_begin if kind == "rectified" else self.L.gpc_hip_stereo_match_begin
+            self._ck(fn(self.h, _ptr(sl), _ptr(gl), _ptr(ml), len(ml), _ptr(sr), _ptr(gr), _ptr(mr), len(mr), W, H, C.byref(s_)))
+            dtype = SUPPORT_DTYPE if kind == "rectified" else CORR_DTYPE
+        cap = cap if cap is not None else W * H
+        out = np.empty(max(cap, 1), dtype)
+        n, nl, nr = C.c_int(), C.c_int(-1), C.c_int(-1)
+        st = self._ck(self.L.gpc_hip_match_fetch(self.h, _ptr(out), cap, C.byref(n), C.byref(nl), C.byref(nr)), allow=(E_CAPACITY,))
+        if st == E_CAPACITY:     # the results stay until the next call: fetch again with room for all of them
+            big = np.empty(n.value, dtype)
+            self._ck(self.L.gpc_hip_match_fetch(self.h, _ptr(big), n.value, C.byref(n), C.byref(nl), C.byref(nr)))
+            assert np.array_equal(big[:cap].view(np.uint8), out[:cap].view(np.uint8))
+        return out[:min(n.value, cap)].copy(), n.value, st, ((nl.value, nr.value) if kind == "pair" else None)
 
     def resident_hits(self):
         return self.L.gpc_hip_resident_hits(self.h)

@@ -258,8 +258,16 @@ struct gpc_hip_ctx {
   // page-locked staging of gpc_hip_preprocess_begin / _fetch: [raw | smooth | grad | mask | count]
   uint8_t* h_pre = nullptr;
   size_t h_pre_cap = 0;
-  int pre_slot = -1, pre_W = 0, pre_H = 0, pre_nmask = 0;  // what _begin left for _fetch
+  int pre_slot = -1, pre_W = 0, pre_H = 0;  // what _begin left for _fetch
   bool pre_have_mask = false;
+  hipEvent_t e_pre = nullptr;   // smooth and grad of that image have landed in the staging block
+  // what gpc_hip_*_match_begin left for gpc_hip_match_fetch: results in the transfer arena (or, `direct`, already in the
+  // caller's page-locked array), the count and the candidate counts in h_cnt[0 .. 2]
+  struct PendingMatch {
+    bool active = false, direct = false, have_ncand = false;
+    size_t esz = 0;
+    int cap_dev = 0;
+  } pend;
   bool debug = false;           // GPC_HIP_DEBUG: launch geometry on stderr
   bool debug_plan = false;      // GPC_HIP_DEBUG_PLAN: the hash-table planner's choice on stderr
 };
@@ -1780,6 +1788,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
     }
   }
   if (c->e_flag) (void)hipEventDestroy(c->e_flag);
+  if (c->e_pre) (void)hipEventDestroy(c->e_pre);
   if (c->s_aux) {
     (void)hipStreamDestroy(c->s_aux);
     (void)hipEventDestroy(c->e_fork);
@@ -1973,22 +1982,15 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
 // grad and the candidate list in page-locked staging memory of the context -- the device writes them there over the link
 // itself -- and says how many candidates there are; _fetch copies them into the caller's arrays (which can be sized by
 // then) and remembers those arrays as the host copies of an image that is still on the device (resident_slot).
-static double dbg_now_ms() {
-  timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
-
-static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr, bool want_mask, int* n_mask) {
+static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr, bool want_mask) {
   if (!c || !raw) return GPC_E_INVALID;
-  const double dbg_t0 = c->debug ? dbg_now_ms() : 0.;
-  double dbg_t1 = 0., dbg_t2 = 0., dbg_t3 = 0.;
   if (thr < 0 || thr > 255) return GPC_E_INVALID;
   CHK(check_dims(W, H));
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)W * H;
   const size_t maxcand = (size_t)(W - 2 * GPC_R) * (H - 2 * GPC_R);
   c->pre_slot = -1;
+  c->pend.active = false;
   if (n != c->res_n || !c->res_smooth.p) {  // another image size: both resident images go
     {
       std::lock_guard<std::mutex> g(g_res_mu);
@@ -1998,8 +2000,9 @@ static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, in
     CHK(ensure(c, c->res_grad, 2 * n));
     c->res_n = n;
   }
+  if (!c->e_pre) HIPCHK(c, hipEventCreateWithFlags(&c->e_pre, hipEventDisableTiming));
   // staging: raw | smooth | grad | mask (every candidate a pixel can be) | count   (all offsets multiples of 16)
-  const size_t mask_bytes = (sizeof(int32_t) * maxcand + 15) & ~(size_t)15;
+  const size_t mask_bytes = pad16(sizeof(int32_t) * maxcand);
   const size_t need = 3 * n + mask_bytes + 64;
   if (need > c->h_pre_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2009,11 +2012,6 @@ static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, in
     HIPCHK(c, hipHostMalloc((void**)&c->h_pre, need + need / 8, hipHostMallocDefault));
     c->h_pre_cap = need + need / 8;
   }
-  uint8_t* h_raw = c->h_pre;
-  uint8_t* h_smooth = h_raw + n;
-  uint8_t* h_grad = h_smooth + n;
-  int32_t* h_mask = reinterpret_cast<int32_t*>(h_grad + n);
-  int32_t* h_count = reinterpret_cast<int32_t*>(h_grad + n + mask_bytes);
   uint8_t* d_stage = nullptr;  // the device's view of the staging block
   HIPCHK(c, hipHostGetDevicePointer((void**)&d_stage, c->h_pre, 0));
   const int slot = c->res_next;
@@ -2026,21 +2024,18 @@ static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, in
   CHK(ensure(c, c->raw, n));
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * 2));
   // the image: a page-locked one is read where it lies, a pageable one (ndb::Buffer, std::vector) passes through staging
-  if (c->debug) dbg_t1 = dbg_now_ms();
   const uint8_t* v_raw = static_cast<const uint8_t*>(device_view_of_host(raw));
-  if (c->debug) dbg_t2 = dbg_now_ms();
   if (!v_raw || ((uintptr_t)v_raw & 15u)) {
-    memcpy(h_raw, raw, n);
+    memcpy(c->h_pre, raw, n);
     v_raw = d_stage;
   }
-  if (c->debug) dbg_t3 = dbg_now_ms();
-  const unsigned n16 = (unsigned)(n / 16);
-  hipLaunchKernelGGL(gpc::k_upload2, dim3((n16 + 255) / 256, 1), dim3(256), 0, c->stream, (const uint4*)v_raw, (const uint4*)v_raw,
-                     (uint4*)c->raw.p, (uint4*)c->raw.p, n16);
+  CHK(dev_copy16(c, c->raw.p, v_raw, n));
   CHK(run_preprocess(c, (const uint8_t*)c->raw.p, nullptr, W, H, 1, 1, thr, false, d_sm, d_gr));
   // smooth and grad leave over the link while the candidate list is made
+  const unsigned n16 = (unsigned)(n / 16);
   hipLaunchKernelGGL(gpc::k_upload2, dim3((n16 + 255) / 256, 2), dim3(256), 0, c->stream, (const uint4*)d_sm, (const uint4*)d_gr,
                      (uint4*)(d_stage + n), (uint4*)(d_stage + 2 * n), n16);
+  HIPCHK(c, hipEventRecord(c->e_pre, c->stream));
   if (want_mask) {
     CHK(ensure(c, c->rowcnt, sizeof(int32_t) * (size_t)H * 2));
     dim3 grid(H - 2 * GPC_R, 1);
@@ -2051,45 +2046,40 @@ static int preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, in
                        reinterpret_cast<int32_t*>(d_stage + 3 * n + mask_bytes));
   }
   HIPCHK(c, hipGetLastError());
-  const double dbg_t4 = c->debug ? dbg_now_ms() : 0.;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->debug)
-    fprintf(stderr, "[gpc_hip] preprocess_begin: set-up %.3f ms, pointer query %.3f, image into staging %.3f, launches %.3f, wait %.3f\n",
-            dbg_t1 - dbg_t0, dbg_t2 - dbg_t1, dbg_t3 - dbg_t2, dbg_t4 - dbg_t3, dbg_now_ms() - dbg_t4);
-  (void)h_mask;
   c->pre_slot = slot;
   c->pre_W = W;
   c->pre_H = H;
   c->pre_have_mask = want_mask;
-  c->pre_nmask = want_mask ? h_count[0] : 0;
-  if (n_mask) *n_mask = c->pre_nmask;
   return GPC_OK;
 }
 
-static int preprocess_fetch(gpc_hip_ctx* c, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap) {
+static int preprocess_fetch(gpc_hip_ctx* c, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap, int* n_mask) {
   if (!c || c->pre_slot < 0 || mask_cap < 0) return GPC_E_INVALID;
   const int slot = c->pre_slot, W = c->pre_W, H = c->pre_H;
   c->pre_slot = -1;
   const size_t n = (size_t)W * H;
   const size_t maxcand = (size_t)(W - 2 * GPC_R) * (H - 2 * GPC_R);
-  const size_t mask_bytes = (sizeof(int32_t) * maxcand + 15) & ~(size_t)15;
+  const size_t mask_bytes = pad16(sizeof(int32_t) * maxcand);
   const uint8_t* h_smooth = c->h_pre + n;
   const uint8_t* h_grad = h_smooth + n;
   const int32_t* h_mask = reinterpret_cast<const int32_t*>(h_grad + n);
-  (void)mask_bytes;
-  const int cnt = c->pre_nmask;
-  const int ncopy = (mask && c->pre_have_mask) ? (cnt < mask_cap ? cnt : mask_cap) : 0;
+  const int32_t* h_count = reinterpret_cast<const int32_t*>(h_grad + n + mask_bytes);
   {
     std::lock_guard<std::mutex> g(g_res_mu);  // whatever these arrays were the host copies of, they are no longer
     drop_overlapping(smooth, smooth ? n : 0);
     drop_overlapping(grad, grad ? n : 0);
-    drop_overlapping(mask, sizeof(int32_t) * (size_t)ncopy);
+    drop_overlapping(mask, sizeof(int32_t) * (size_t)(mask ? mask_cap : 0));
   }
-  const size_t total = (smooth ? n : 0) + (grad ? n : 0) + sizeof(int32_t) * (size_t)ncopy;
-  const bool par = total >= 512 * 1024;
+  const bool par = n >= 128 * 1024;
   if (par) CHK(ensure_pool(c));
+  // the two images first (they have landed when e_pre has passed), the candidate list when the stream is done
+  HIPCHK(c, hipEventSynchronize(c->e_pre));
   if (smooth) host_copy(c, smooth, h_smooth, n, par);
   if (grad) host_copy(c, grad, h_grad, n, par);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int cnt = c->pre_have_mask ? h_count[0] : 0;
+  if (n_mask) *n_mask = cnt;
+  const int ncopy = (mask && c->pre_have_mask) ? (cnt < mask_cap ? cnt : mask_cap) : 0;
   if (ncopy) host_copy(c, mask, h_mask, sizeof(int32_t) * (size_t)ncopy, par);
   uint64_t fp = 0;
   const bool record = c->resident_mode && smooth && grad && c->pre_have_mask && (mask || cnt == 0) && cnt <= mask_cap;
@@ -2112,18 +2102,18 @@ static int preprocess_fetch(gpc_hip_ctx* c, uint8_t* smooth, uint8_t* grad, int3
   return (mask && c->pre_have_mask && cnt > mask_cap) ? GPC_E_CAPACITY : GPC_OK;
 }
 
-int gpc_hip_preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr, int* n_mask) {
-  return preprocess_begin(c, raw, W, H, thr, true, n_mask);
+int gpc_hip_preprocess_begin(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr) {
+  return preprocess_begin(c, raw, W, H, thr, true);
 }
 
-int gpc_hip_preprocess_fetch(gpc_hip_ctx* c, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap) {
-  return preprocess_fetch(c, smooth, grad, mask, mask_cap);
+int gpc_hip_preprocess_fetch(gpc_hip_ctx* c, uint8_t* smooth, uint8_t* grad, int32_t* mask, int mask_cap, int* n_mask) {
+  return preprocess_fetch(c, smooth, grad, mask, mask_cap, n_mask);
 }
 
 int gpc_hip_preprocess(gpc_hip_ctx* c, const uint8_t* raw, int W, int H, int thr, uint8_t* smooth,
                        uint8_t* grad, int32_t* mask, int mask_cap, int* n_mask) {
-  CHK(preprocess_begin(c, raw, W, H, thr, n_mask || mask, n_mask));
-  return preprocess_fetch(c, smooth, grad, mask, mask ? mask_cap : 0);
+  CHK(preprocess_begin(c, raw, W, H, thr, n_mask || mask));
+  return preprocess_fetch(c, smooth, grad, mask, mask ? mask_cap : 0, n_mask);
 }
 
 int gpc_hip_resident_hits(const gpc_hip_ctx* c) { return c ? c->resident_hits : 0; }
@@ -2162,28 +2152,29 @@ int gpc_hip_hash_codes(gpc_hip_ctx* c, const uint8_t* smooth, const uint8_t* gra
 
 static int pinned_counts(gpc_hip_ctx* c, int npairs);
 
-static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
-                              const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
-                              const int32_t* maskR, int nR, int W, int H, const gpc_settings* s, int mode,
-                              void* out, int cap, int* n_out) {
-  if (!c || !smoothL || !gradL || !smoothR || !gradR || !n_out || cap < 0 || (cap > 0 && !out)) return GPC_E_INVALID;
+// Queues hash + match of two preprocessed images; the results go to the transfer arena (cap_dev records at most; the
+// caller's page-locked array instead when direct_out is its device view) and are collected by match_fetch.
+static int match_preprocessed_begin(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
+                                    const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
+                                    const int32_t* maskR, int nR, int W, int H, const gpc_settings* s, int mode,
+                                    int cap_dev, void* direct_out) {
+  if (!c || !smoothL || !gradL || !smoothR || !gradR || cap_dev < 0) return GPC_E_INVALID;
   if ((nL > 0 && !maskL) || (nR > 0 && !maskR) || nL < 0 || nR < 0) return GPC_E_INVALID;
   CHK(check_settings(s));
   CHK(check_dims(W, H));
   CHK(forest_matches(c, W, H));
   HIPCHK(c, hipSetDevice(c->device));
+  c->pend.active = false;
+  c->pre_slot = -1;
   const size_t n = (size_t)W * H;
   const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  if ((uint64_t)cap_dev * esz >= (1ull << 32)) return GPC_E_UNSUPPORTED;  // (beyond 2^30 pixels anyway)
   CHK(ensure(c, c->codes, sizeof(uint32_t) * 2 * n));
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * 2));
   CHK(pinned_counts(c, 1));
   int32_t* d_cnt = nullptr;
   HIPCHK(c, hipHostGetDevicePointer((void**)&d_cnt, c->h_cnt, 0));
-  // Results: a page-locked `out` is written by the matcher itself over the link; a pageable one receives them from the
-  // transfer arena (same writes, then a copy by CPU threads) -- never from hipMemcpy (gpc_hip_ctx::h_xfer)
-  const size_t out_bytes = pad16(esz * (size_t)(cap > 0 ? cap : 1));
-  void* d_out = (cap > 0 && (uint64_t)cap * esz < (1ull << 32)) ? device_view_of_host(out) : nullptr;
-  const bool out_direct = d_out != nullptr;
+  const size_t out_bytes = pad16(esz * (size_t)(cap_dev > 0 ? cap_dev : 1));
   const int sl = resident_slot(c, smoothL, gradL, maskL, nL, W, H);
   const int sr = sl >= 0 ? resident_slot(c, smoothR, gradR, maskR, nR, W, H) : -1;
   const bool resident = sl >= 0 && sr >= 0;
@@ -2191,9 +2182,9 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
   const size_t mL = pad16(sizeof(int32_t) * (size_t)nL), mR = pad16(sizeof(int32_t) * (size_t)nR);
   uint8_t* d_arena = nullptr;
   const size_t in_bytes = resident ? 0 : 4 * n + mL + mR;
-  if (!out_direct || in_bytes) CHK(xfer_reserve(c, (out_direct ? 0 : out_bytes) + in_bytes, &d_arena));
-  const size_t in_off = out_direct ? 0 : out_bytes;
-  if (!out_direct) d_out = d_arena;
+  if (!direct_out || in_bytes) CHK(xfer_reserve(c, (direct_out ? 0 : out_bytes) + in_bytes, &d_arena));
+  const size_t in_off = direct_out ? 0 : out_bytes;
+  void* d_out = direct_out ? direct_out : d_arena;
   const uint8_t* d_sm = nullptr;
   const uint8_t* d_gr = nullptr;
   const uint8_t* d_cand = nullptr;
@@ -2250,20 +2241,51 @@ static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint
   c->grad_is_bits = false;  // byte images
   hipLaunchKernelGGL(gpc::k_stats_init, dim3(1), dim3(64), 0, c->stream, (int32_t*)c->stats.p, 2);
   CHK(run_hash(c, d_sm, d_gr, resident ? nullptr : d_cand, W, H, 2, false, (uint32_t*)c->codes.p));
-  CHK(run_match(c, W, H, 1, s, mode, d_cand, d_out, cap, d_cnt, nullptr));
+  CHK(run_match(c, W, H, 1, s, mode, d_cand, d_out, cap_dev, d_cnt, nullptr));
+  c->pend.active = true;
+  c->pend.direct = direct_out != nullptr;
+  c->pend.have_ncand = false;
+  c->pend.esz = esz;
+  c->pend.cap_dev = cap_dev;
+  return GPC_OK;
+}
+
+// Waits for what a *_begin queued and delivers min(count, cap) records; the true count always.  May be called again
+// (a larger array after GPC_E_CAPACITY) until the next call on the context.
+static int match_fetch(gpc_hip_ctx* c, void* out, int cap, int* n_out, int* ncl, int* ncr) {
+  if (!c || !c->pend.active || !n_out || cap < 0 || (cap > 0 && !out)) return GPC_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   CHK(check_join_err(c));
   const int32_t cnt = c->h_cnt[0];
   *n_out = cnt;
-  const int ncopy = cnt < cap ? cnt : cap;
-  if (!out_direct && ncopy > 0) {
-    const size_t bytes = esz * (size_t)ncopy;
-    const bool par = bytes >= 512 * 1024;
+  if (c->pend.have_ncand) {
+    if (ncl) *ncl = c->h_cnt[1];
+    if (ncr) *ncr = c->h_cnt[2];
+  }
+  int ncopy = cnt < cap ? cnt : cap;
+  if (ncopy > c->pend.cap_dev) ncopy = c->pend.cap_dev;
+  if (!c->pend.direct && ncopy > 0) {
+    const size_t bytes = c->pend.esz * (size_t)ncopy;
+    const bool par = bytes >= 256 * 1024;
     if (par) CHK(ensure_pool(c));
     host_copy(c, out, c->h_xfer, bytes, par);
     if (par) host_copy_wait(c);
   }
-  return cnt > cap ? GPC_E_CAPACITY : GPC_OK;
+  return (cnt > cap || cnt > c->pend.cap_dev) ? GPC_E_CAPACITY : GPC_OK;
+}
+
+static int match_preprocessed(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
+                              const int32_t* maskL, int nL, const uint8_t* smoothR, const uint8_t* gradR,
+                              const int32_t* maskR, int nR, int W, int H, const gpc_settings* s, int mode,
+                              void* out, int cap, int* n_out) {
+  if (!n_out || cap < 0 || (cap > 0 && !out)) return GPC_E_INVALID;
+  // a page-locked `out` is written by the matcher itself over the link
+  const size_t esz = mode == 0 ? sizeof(gpc_support) : sizeof(gpc_correspondence);
+  void* dv = (c && cap > 0 && (uint64_t)cap * esz < (1ull << 32)) ? device_view_of_host(out) : nullptr;
+  CHK(match_preprocessed_begin(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, mode, cap, dv));
+  const int st = match_fetch(c, out, cap, n_out, nullptr, nullptr);
+  c->pend.active = false;
+  return st;
 }
 
 int gpc_hip_rectified_match(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL,
@@ -2278,6 +2300,23 @@ int gpc_hip_stereo_match(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* 
                          const int32_t* maskR, int nR, int W, int H, const gpc_settings* s,
                          gpc_correspondence* out, int cap, int* n_out) {
   return match_preprocessed(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, 1, out, cap, n_out);
+}
+
+// the asynchronous forms: every match of two candidate lists has at most min(nL, nR) results
+int gpc_hip_rectified_match_begin(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL, const int32_t* maskL, int nL,
+                                  const uint8_t* smoothR, const uint8_t* gradR, const int32_t* maskR, int nR, int W, int H,
+                                  const gpc_settings* s) {
+  return match_preprocessed_begin(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, 0, (nL < nR ? nL : nR) + 1, nullptr);
+}
+
+int gpc_hip_stereo_match_begin(gpc_hip_ctx* c, const uint8_t* smoothL, const uint8_t* gradL, const int32_t* maskL, int nL,
+                               const uint8_t* smoothR, const uint8_t* gradR, const int32_t* maskR, int nR, int W, int H,
+                               const gpc_settings* s) {
+  return match_preprocessed_begin(c, smoothL, gradL, maskL, nL, smoothR, gradR, maskR, nR, W, H, s, 1, (nL < nR ? nL : nR) + 1, nullptr);
+}
+
+int gpc_hip_match_fetch(gpc_hip_ctx* c, void* out, int cap, int* n_out, int* n_cand_l, int* n_cand_r) {
+  return match_fetch(c, out, cap, n_out, n_cand_l, n_cand_r);
 }
 
 // ------------------------------------------------------------------ batch entry points
@@ -2816,6 +2855,51 @@ int gpc_hip_match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_
 int gpc_hip_host_threads(const gpc_hip_ctx* c) { return c ? c->pool.size() : 0; }
 int gpc_hip_host_numa_node(const gpc_hip_ctx* c) { return (c && c->have_node_cpus) ? c->numa_node : -1; }
 
+// The whole timed region of samples/sparsematch.cpp:45-52 for one pair, queued: images through the arena (or read where
+// they lie when page-locked), the batched pipeline for one pair, results into the arena for gpc_hip_match_fetch.
+int gpc_hip_match_pair_begin(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, const gpc_settings* s) {
+  if (!c || !rawL || !rawR) return GPC_E_INVALID;
+  CHK(check_settings(s));
+  CHK(check_dims(W, H));
+  CHK(forest_matches(c, W, H));
+  HIPCHK(c, hipSetDevice(c->device));
+  c->pend.active = false;
+  c->pre_slot = -1;
+  const size_t n = (size_t)W * H;
+  const int cap_dev = (W - 2 * GPC_R) * (H - 2 * GPC_R) + 1;  // no pair has more supports than an image has candidates
+  const size_t out_bytes = pad16(sizeof(gpc_support) * (size_t)cap_dev);
+  CHK(ensure(c, c->raw, 2 * n));
+  CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2));
+  CHK(pinned_counts(c, 1));
+  int32_t* d_cnt = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer((void**)&d_cnt, c->h_cnt, 0));
+  uint8_t* d_arena = nullptr;
+  CHK(xfer_reserve(c, out_bytes + 2 * n, &d_arena));
+  const uint8_t* vL = static_cast<const uint8_t*>(device_view_of_host(rawL));
+  const uint8_t* vR = vL ? static_cast<const uint8_t*>(device_view_of_host(rawR)) : nullptr;
+  if (!vL || !vR || (((uintptr_t)vL | (uintptr_t)vR) & 15u)) {
+    memcpy(c->h_xfer + out_bytes, rawL, n);
+    memcpy(c->h_xfer + out_bytes + n, rawR, n);
+    vL = d_arena + out_bytes;
+    vR = vL + n;
+  }
+  uint8_t* d_l = (uint8_t*)c->raw.p;
+  uint8_t* d_r = d_l + n;
+  const unsigned n16 = (unsigned)(n / 16);
+  hipLaunchKernelGGL(gpc::k_upload2, dim3((n16 + 255) / 256, 2), dim3(256), 0, c->stream, (const uint4*)vL, (const uint4*)vR,
+                     (uint4*)d_l, (uint4*)d_r, n16);
+  HIPCHK(c, hipGetLastError());
+  CHK(run_preprocess(c, d_l, d_r, W, H, 1, 2, s->gradient_threshold, true));
+  CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2, false, (uint32_t*)c->codes.p));
+  CHK(run_match(c, W, H, 1, s, 0, (const uint8_t*)c->grad.p, d_arena, cap_dev, d_cnt, d_cnt + 1));
+  c->pend.active = true;
+  c->pend.direct = false;
+  c->pend.have_ncand = true;
+  c->pend.esz = sizeof(gpc_support);
+  c->pend.cap_dev = cap_dev;
+  return GPC_OK;
+}
+
 int gpc_hip_match_pair(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H,
                        const gpc_settings* s, gpc_support* out, int cap, int* n_out, int* n_cand_l,
                        int* n_cand_r) {
@@ -2867,10 +2951,11 @@ int gpc_hip_warmup(gpc_hip_ctx* c, int W, int H, const gpc_settings* settings) {
     int nm[2] = {0, 0};
     const uint8_t* raw[2] = {L, R};
     const int thr = settings ? settings->gradient_threshold : 5;
+    const int maxcand = (W - 2 * GPC_R) * (H - 2 * GPC_R);
     for (int side = 0; side < 2 && st == GPC_OK; ++side) {
-      st = gpc_hip_preprocess_begin(c, raw[side], W, H, thr, &nm[side]);
-      mk[side].resize((size_t)nm[side] + 1);
-      if (st == GPC_OK) st = gpc_hip_preprocess_fetch(c, sm[side].data(), gr[side].data(), mk[side].data(), nm[side]);
+      st = gpc_hip_preprocess_begin(c, raw[side], W, H, thr);
+      mk[side].resize((size_t)maxcand + 1);
+      if (st == GPC_OK) st = gpc_hip_preprocess_fetch(c, sm[side].data(), gr[side].data(), mk[side].data(), maxcand, &nm[side]);
     }
     gpc_settings modes[4];
     int nmodes = 0;
@@ -2890,6 +2975,8 @@ int gpc_hip_warmup(gpc_hip_ctx* c, int W, int H, const gpc_settings* settings) {
       int32_t cnt = 0, nc[2];
       if (st == GPC_OK) st = gpc_hip_match_batch(c, L, R, W, H, 1, &modes[k], pout, (int)cap, &cnt, nc);                 // page-locked
       if (st == GPC_OK || st == GPC_E_CAPACITY) st = gpc_hip_match_batch(c, sm[0].data(), sm[1].data(), W, H, 1, &modes[k], out.data(), (int)out.size(), &cnt, nc);  // pageable
+      if (st == GPC_OK || st == GPC_E_CAPACITY) st = gpc_hip_match_pair_begin(c, sm[0].data(), sm[1].data(), W, H, &modes[k]);   // Forest::matchPair
+      if (st == GPC_OK) st = gpc_hip_match_fetch(c, out.data(), (int)out.size(), &ns, nullptr, nullptr);
       if (st == GPC_E_CAPACITY) st = GPC_OK;
     }
     c->resident_mode = keep;

@@ -150,10 +150,10 @@ def test_overwritten_and_foreign_arrays(oracle, forest_paths):
         pl, pr = a.preprocess_resident(L, 5), a.preprocess_resident(R, 5)
         # another context delivers a different image INTO the arrays context a remembers as L's host copies
         n = C.c_int()
-        assert b.L.gpc_hip_preprocess_begin(b.h, _ptr(T), W, H, 5, C.byref(n)) == 0
-        m = min(n.value, len(pl[2]))
-        st = b.L.gpc_hip_preprocess_fetch(b.h, _ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), len(pl[2]))
+        assert b.L.gpc_hip_preprocess_begin(b.h, _ptr(T), W, H, 5) == 0
+        st = b.L.gpc_hip_preprocess_fetch(b.h, _ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), len(pl[2]), C.byref(n))
         assert st in (0, g.capi.E_CAPACITY)
+        m = min(n.value, len(pl[2]))
         tl = (pl[0], pl[1], pl[2][:m])
         ha, hb = a.resident_hits(), b.resident_hits()
         supp, _, _ = a.rectified_match(tl, pr, gs)
@@ -204,3 +204,36 @@ def test_warmup_every_mode_and_sizes(ctx, oracle, forest_paths):
         assert e.value.status == g.capi.E_NO_FOREST
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("epipolar,hashtable", [(1, 0), (0, 0), (1, 1), (0, 1)])
+def test_two_step_forms(ctx, oracle, forest_paths, epipolar, hashtable):
+    """gpc_hip_*_match_begin + gpc_hip_match_fetch (what the C++ API calls): the synchronous calls' results, short
+    capacities answered with the true count and fetched again, candidate counts of the pair form."""
+    import opengpc_amd as g
+    W, H = 272, 61
+    L, R = oracle.synth_pair(W, H, 3, 9)
+    ctx.load_forest(forest_paths["tau"], W, H)
+    rc, f = oracle.read_forest(forest_paths["tau"], W, H)
+    gs = g.Settings(5, 64, 1, bool(epipolar), bool(hashtable), 1)
+    os_ = sparsematch_settings(5, 64, 1, bool(epipolar), bool(hashtable), False)
+    want, nl, nr = oracle.match_pair(L, R, f, os_)
+    supp, n, st, nc = ctx.match_async("pair", L, R, gs)
+    assert st == 0 and nc == (nl, nr) and n == len(want) and np.array_equal(supp, want)
+    supp, n, st, nc = ctx.match_async("pair", L, R, gs, cap=max(len(want) // 2, 1))
+    assert st == g.capi.E_CAPACITY and n == len(want) and np.array_equal(supp, want[:max(len(want) // 2, 1)])
+    pl, pr = ctx.preprocess_resident(L, 5), ctx.preprocess_resident(R, 5)
+    h0 = ctx.resident_hits()
+    supp, n, st, _ = ctx.match_async("rectified", pl, pr, gs)
+    assert st == 0 and np.array_equal(supp, want) and ctx.resident_hits() == h0 + 1
+    corr, nc_, st, _ = ctx.match_async("stereo", pl, pr, gs)
+    wcorr = oracle_from_preprocessed(oracle, pl, pr, f, W, os_, bool(epipolar), bool(hashtable))[0]
+    assert st == 0 and np.array_equal(corr.view(np.int32), wcorr.view(np.int32))
+    cl, cr = tuple(a.copy() for a in pl), tuple(a.copy() for a in pr)      # the upload path
+    supp, n, st, _ = ctx.match_async("rectified", cl, cr, gs, cap=3)
+    assert st == g.capi.E_CAPACITY and n == len(want) and np.array_equal(supp, want[:3]) and ctx.resident_hits() == h0 + 2
+    # a fetch without a begin is refused
+    import ctypes as C
+    k = C.c_int()
+    ctx.match_pair(L, R, gs)
+    assert ctx.L.gpc_hip_preprocess_fetch(ctx.h, None, None, None, 0, C.byref(k)) == g.capi.E_INVALID
