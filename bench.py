@@ -316,6 +316,32 @@ def main():
     counts = d_counts.cpu().numpy().astype(np.int64)
     ncand = d_ncand.cpu().numpy().astype(np.int64)
 
+    # ---- BASELINE configs[3] AS WRITTEN: ONE batch of 256 pairs shared by the N GPUs, 256 / N pairs per rank and step
+    #      (the headline above scales weakly: 256 pairs per rank at any N).  The same barrier-bracketed windows, fewer of
+    #      them; at one rank also the 32-pair step that is a rank's share at N = 8.  Not part of `value`.
+    strong_windows, share8_windows = [], []
+    Bs = max(1, min(B, 256 // world))
+    if not args.no_extras or args.host_path:
+        def step_n(npairs):
+            def f():
+                ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, npairs, settings, d_outs[-1].data_ptr(), cap,
+                                       d_cnts[-1].data_ptr(), d_ncs[-1].data_ptr())
+            return f
+        for _ in range(5):
+            step_n(Bs)()
+        device_sync()
+        strong_windows = [gdist.timed_steps(step_n(Bs), args.steps, device_sync) for _ in range(40)]
+        if world == 1 and B >= 32:
+            for _ in range(5):
+                step_n(32)()
+            device_sync()
+            share8_windows = [gdist.timed_steps(step_n(32), args.steps, device_sync) for _ in range(40)]
+        # (d_outs[-1] was overwritten by shorter batches: the arrays compared below are d_out's, written by the timed windows)
+        if P == 1:
+            ctx.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, B, settings, d_out.data_ptr(), cap,
+                                   d_counts.data_ptr(), d_ncand.data_ptr())
+            device_sync()
+
     # ---- parity gate on the bench's own data: pairs spread over this rank's batch against the oracle
     #      (checker only; the -O3 build of the C restatement, held equal to the plain build by tests/)
     n_verified, verified = 0, None
@@ -342,7 +368,9 @@ def main():
     #      (the ranks of a node share the host's memory bandwidth and CPUs, so they are timed together); the slowest
     #      rank of a repetition counts.  The host API has no torch dependency, and a process that has imported torch runs
     #      every HIP library on the ROCm runtime bundled with the torch wheel (an older one than the /opt/rocm this library
-    #      is built against; its copies are slower: 8.7 vs 5.6 ms per 256 pairs).  So every rank makes the calls in a
+    #      is built against).  Which of the two legs is the slower one has swapped between rounds (r03: this process 8.7 ms,
+    #      child 5.6; r04: child 8.5, this process 6.6), so the line carries the stages of every leg, the CPUs the workers
+    #      ran on and the NUMA node the buffers' pages lie on (pcie_inclusive.stages / .host / .pages_on_node).  Every rank makes the calls in a
     #      CHILD process without torch -- the C++ caller's situation -- and this process only carries the barriers and
     #      tells the child when to go.  At one rank the same call is also timed inside this process, for the record.
     host_reps, host_times, host_ok, host_threads, child_rec = 15, [], True, 0, None
@@ -380,11 +408,19 @@ def main():
             outb = ctx.pinned_empty((B, capi_cap), g.SUPPORT_DTYPE)
             res = {}
 
+            inproc_stages = []
+
             def host_call():
                 res["r"] = ctx.match_batch(Lp, Rp, settings, capi_cap, out=outb)
+                inproc_stages.append(ctx.batch_stages())
             for _ in range(3):
                 host_call()
+            del inproc_stages[:]
             inproc_times = sorted(gdist.timed_calls(host_call, 9))
+            from opengpc_amd.hostinfo import cpu_nodes, current_cpu, pages_nodes, stage_summary
+            inproc_info = {"stages_ms": stage_summary(inproc_stages), "pages_on_node": {"out": pages_nodes(outb), "images": pages_nodes(Lp)},
+                           "worker_cpus": ctx.worker_cpus(), "calling_thread_cpu": current_cpu(),
+                           "calling_thread_node": cpu_nodes().get(current_cpu(), -1)}
             o_, c_, n_, st_ = res["r"]
             host_ok = host_ok and bool(st_ == 0 and np.array_equal(c_.astype(np.int64), counts))
             del Lp, Rp, outb
@@ -394,6 +430,15 @@ def main():
            float(n_verified), 1.0 if host_ok else 0.0, float(host_threads)] + [float(t) for t in host_times] + \
           [float(t) for t in packed_times] + [float(t) for t in windows]
     allr = gdist.gather_stats(row, device=stat_dev).numpy()
+    strong = None
+    if strong_windows:
+        sw = np.sort(gdist.gather_stats(strong_windows, device=stat_dev).numpy().max(axis=0))   # per window: the slowest rank
+        ts = float(sw[len(sw) // 2]) / args.steps
+        strong = {"pairs_per_rank_per_step": Bs, "pairs_per_step": Bs * world, "ms_per_step": round(ts * 1e3, 4),
+                  "value": round(2.0 * W * H * Bs * world / ts / 1e6, 1), "unit": "Mpix/s",
+                  "ms_per_step_min": round(float(sw[0]) / args.steps * 1e3, 4), "ms_per_step_max": round(float(sw[-1]) / args.steps * 1e3, 4),
+                  "note": "BASELINE configs[3] as written: one batch of 256 pairs over the %d GPU(s), %d pairs per rank and step, "
+                          "device-resident like `value`; median of %d windows of %d steps" % (world, Bs, len(sw), args.steps)}
     if float(allr[:, 3].min()) < 1.0:
         raise SystemExit("bench.py: GPU supports differ from the oracle on some rank -- refusing to report a number")
     nh, npk = len(host_times), len(packed_times)
@@ -509,11 +554,19 @@ def main():
             pcie["timed_region"] = "host images -> host gpc_support arrays (sparsematch.cpp:45-52), median of %d calls after 5 untimed" % nh
             if child_rec:
                 single_h2h = child_rec.pop("single_pair_host_to_host", None)
-                for k in ("host_buffers", "bytes_in", "bytes_over_the_link_out", "bytes_delivered", "host"):
+                for k in ("host_buffers", "bytes_in", "bytes_over_the_link_out", "bytes_delivered", "host", "pages_on_node"):
                     if k in child_rec:
                         pcie[k + ("_rank0" if world > 1 and k != "host_buffers" else "")] = child_rec[k]
+                # where a call's time goes (host clock, ms since entry, medians): the stages of the expanded call, and of
+                # the packed call of the same child beside it (the same pipeline without the expansion)
+                pcie["stages"] = {"expanded": child_rec.get("stages_ms"), "packed": child_rec.get("packed", {}).get("stages_ms"),
+                                  "note": "ms since the call's entry when the host saw: the last chunk's upload complete, the "
+                                          "last chunk's kernels done, the last chunk of packed records landed in host memory, "
+                                          "the delivery done (gpc_hip_batch_stages); rank 0's child"}
             if inproc_times:
                 ti = inproc_times[len(inproc_times) // 2]
+                pcie["stages"]["in_this_process"] = inproc_info.get("stages_ms")
+                pcie["in_this_process_host"] = {k: v for k, v in inproc_info.items() if k != "stages_ms"}
                 pcie["in_this_process"] = {"ms_per_call": round(ti * 1e3, 3), "value": round(2.0 * W * H * B / ti / 1e6, 1),
                                            "unit": "Mpix/s", "ms_per_call_min": round(inproc_times[0] * 1e3, 3),
                                            "ms_per_call_max": round(inproc_times[-1] * 1e3, 3),
@@ -614,7 +667,19 @@ def main():
             "host_to_host_all_ranks": host_all,
             "host_to_host_packed_all_ranks": host_packed,
             "two_stream_pipeline": two,
+            "strong_256": strong,
         }
+        if strong:
+            # against N times what ONE of these GPUs does on 256 pairs (the weak-scaling value / N)
+            strong["efficiency_vs_n_times_one_gpu_256_pairs"] = round(strong["value"] / value, 4)
+        if share8_windows:
+            s8 = sorted(share8_windows)
+            t8 = s8[len(s8) // 2] / args.steps
+            line["strong_256_share_at_8_gpus"] = {
+                "pairs_per_step": 32, "ms_per_step": round(t8 * 1e3, 4), "value": round(2.0 * W * H * 32 / t8 / 1e6, 1), "unit": "Mpix/s",
+                "fraction_of_the_256_pair_rate": round(2.0 * W * H * 32 / t8 / 1e6 / value, 4),
+                "note": "a rank's share of configs[3] at 8 GPUs (32 pairs per step) on this one GPU: what the strong-scaling "
+                        "leg of an 8-GPU run costs per rank"}
         if cpu:
             # like with like: the CPU leg is host -> host, so is pcie_inclusive
             if pcie:

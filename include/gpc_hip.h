@@ -235,6 +235,16 @@ int gpc_hip_match_batch(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* ra
  * settings->num_threads if > 1, else the CPUs this process may use -- divided by LOCAL_WORLD_SIZE when a launcher
  * starts one process per GPU -- less the feeding thread, between 2 and 8. */
 int gpc_hip_host_threads(const gpc_hip_ctx* ctx);
+/* Where the last gpc_hip_match_batch / gpc_hip_match_batch_packed call of the context spent its time: the host's clock,
+ * in ms since the call's entry, when it saw [0] the last chunk's upload complete, [1] the last chunk's kernels done (its
+ * counts arrived), [2] the last chunk of packed records landed in host memory, [3] the expansion / delivery done (the
+ * call returned).  All 0 for calls that took another path (one or two pairs written directly, the device-wide matchers). */
+int gpc_hip_batch_stages(const gpc_hip_ctx* ctx, float* ms4);
+/* The CPU each worker thread last ran a job on (returns the number of workers; fills at most cap entries). */
+int gpc_hip_host_worker_cpus(gpc_hip_ctx* ctx, int* cpus, int cap);
+/* Batch calls of this context that ran their chunk pipeline on a thread bound to the GPU's NUMA node because the caller's
+ * thread was on another socket (GPC_HIP_NO_FEEDER=1: never). */
+int gpc_hip_fed_calls(const gpc_hip_ctx* ctx);
 /* The NUMA node of the host this context's GPU hangs off (the expansion workers are bound to its CPUs), -1 if unknown. */
 int gpc_hip_host_numa_node(const gpc_hip_ctx* ctx);
 

@@ -75,7 +75,7 @@ SYMBOLS = [
     "gpc_hip_rectified_match_begin", "gpc_hip_stereo_match_begin", "gpc_hip_match_pair_begin", "gpc_hip_match_fetch",
     "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
     "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
-    "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node",
+    "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node", "gpc_hip_batch_stages", "gpc_hip_host_worker_cpus", "gpc_hip_fed_calls",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
     "gpc_hip_train_set_create", "gpc_hip_train_set_destroy", "gpc_hip_train_set_size", "gpc_hip_train_set_marks",
@@ -142,6 +142,9 @@ def load():
     L.gpc_hip_expand_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.gpc_hip_host_threads.argtypes = [C.c_void_p]
     L.gpc_hip_host_numa_node.argtypes = [C.c_void_p]
+    L.gpc_hip_fed_calls.argtypes = [C.c_void_p]
+    L.gpc_hip_batch_stages.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.gpc_hip_host_worker_cpus.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.gpc_hip_set_kernel_timing_mask.argtypes = [C.c_void_p, C.c_uint]
     L.gpc_hip_reset_kernel_timing.argtypes = [C.c_void_p]
@@ -340,6 +343,18 @@ class Context:
             self._ck(self.L.gpc_hip_match_fetch(self.h, _ptr(big), n.value, C.byref(n), C.byref(nl), C.byref(nr)))
             assert np.array_equal(big[:cap].view(np.uint8), out[:cap].view(np.uint8))
         return out[:min(n.value, cap)].copy(), n.value, st, ((nl.value, nr.value) if kind == "pair" else None)
+
+    def batch_stages(self):
+        """ms since entry of the last match_batch / match_batch_packed call: upload seen done, kernels done, last packed
+        chunk landed, delivery done (gpc_hip_batch_stages)."""
+        a = (C.c_float * 4)()
+        self.L.gpc_hip_batch_stages(self.h, a)
+        return [float(v) for v in a]
+
+    def worker_cpus(self):
+        a = (C.c_int * 64)()
+        n = self.L.gpc_hip_host_worker_cpus(self.h, a, 64)
+        return [int(a[i]) for i in range(min(n, 64))]
 
     def resident_hits(self):
         return self.L.gpc_hip_resident_hits(self.h)

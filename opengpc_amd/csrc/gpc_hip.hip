@@ -97,10 +97,11 @@ class ExpandPool {
     quit_ = false;
     have_bind_ = bind != nullptr;
     if (bind) bind_ = *bind;
+    cpus_.assign((size_t)nthreads, -1);
     for (int i = 0; i < nthreads; ++i)
-      threads_.emplace_back([this] {
+      threads_.emplace_back([this, i] {
         if (have_bind_) (void)sched_setaffinity(0, sizeof bind_, &bind_);
-        run();
+        run(i);
       });
   }
   void stop() {
@@ -128,10 +129,18 @@ class ExpandPool {
     for (int s = 0; s < 8; ++s) wait_slot(s);
   }
   int size() const { return (int)threads_.size(); }
+  // the CPU every worker last ran a job on (diagnostics: gpc_hip_host_worker_cpus)
+  int worker_cpus(int* out, int cap) {
+    std::lock_guard<std::mutex> g(m_);
+    int n = 0;
+    for (size_t i = 0; i < cpus_.size() && n < cap; ++i) out[n++] = cpus_[i];
+    return (int)cpus_.size();
+  }
 
  private:
-  void run();
+  void run(int index);
   std::vector<std::thread> threads_;
+  std::vector<int> cpus_;
   std::deque<ExpandJob> q_;
   std::mutex m_;
   std::condition_variable cv_, done_;
@@ -161,6 +170,10 @@ struct gpc_hip_ctx {
   int32_t* h_cnt = nullptr;       // page-locked landing area of counts [npairs] + candidate counts [npairs][2]: a copy to the
   size_t h_cnt_cap = 0;           // caller's (pageable) arrays would block the host until the chunk's kernels are done
   ExpandPool pool;
+  // host clock at the stages of the last gpc_hip_match_batch / _packed call, ms since its entry (gpc_hip_batch_stages):
+  // [0] last upload seen complete, [1] last chunk's kernels done (its counts have arrived), [2] last chunk of packed
+  // records has landed in host memory, [3] expansion / delivery done (the call returns)
+  float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};
   bool grad_is_bits = false;      // c->grad holds k_preprocess's bit image (set by run_preprocess, read by run_hash)
   bool no_grad_bits = false;      // GPC_HIP_NO_GRAD_BITS: the batched pipelines keep the byte image (A/B checks)
   int upload_mode = 1;            // GPC_HIP_UPLOAD: single-pair host path -- 0: hipMemcpyAsync per side, 1: one k_upload2 launch, 2: k_preprocess reads the host's pages
@@ -169,6 +182,8 @@ struct gpc_hip_ctx {
   bool have_node_cpus = false;    // CPUs of the NUMA node this GPU hangs off (from sysfs), within the process's affinity mask
   cpu_set_t node_cpus;
   int numa_node = -1;
+  bool no_feeder = false;         // GPC_HIP_NO_FEEDER: the chunk pipeline always runs on the calling thread (A/B checks)
+  int fed_calls = 0;              // batch calls that ran on a feeder thread (gpc_hip_fed_calls)
   int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
   int expand_threads = 0;         // GPC_HIP_EXPAND_THREADS (tuning)
   char err[256] = {0};
@@ -305,6 +320,12 @@ std::vector<gpc_hip_ctx*> g_ctxs;
     int s_ = (expr);               \
     if (s_ != GPC_OK) return s_;   \
   } while (0)
+
+double host_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 int ensure(gpc_hip_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return GPC_OK;
@@ -510,7 +531,7 @@ void expand_rows(const uint32_t* packed, const int32_t* rows, int y0, int y1, lo
 #endif
 }
 
-void ExpandPool::run() {
+void ExpandPool::run(int index) {
   for (;;) {
     ExpandJob j;
     {
@@ -519,6 +540,7 @@ void ExpandPool::run() {
       if (q_.empty()) return;
       j = q_.front();
       q_.pop_front();
+      cpus_[(size_t)index] = sched_getcpu();
     }
     if (j.copy_bytes) memcpy(j.copy_dst, j.copy_src, j.copy_bytes);
     else expand_rows(j.packed, j.rows, j.y0, j.y1, j.first, j.limit, j.out);
@@ -587,8 +609,10 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   // more workgroups, shorter chains
   const int gx = (W / PP_PX + PP_TX - 1) / PP_TX;
   auto blocks_with = [&](int r) { return (long)gx * ((H + PP_TY * r - 1) / (PP_TY * r)) * nimg; };
+  // (measured per launch, 1024x436: 32 pairs -- 1024 workgroups of 14-row strips, 2432 of 6-row ones -- 23.2 / 21.0 us;
+  //  64 pairs 35.2 / 35.0; 16 pairs take the 6-row strips either way, 2-row ones are slower from 16 pairs on)
   const int rows = c->pre_rows ? c->pre_rows
-                               : (blocks_with(PP_ROWS) >= 1024 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL));
+                               : (blocks_with(PP_ROWS) >= 2048 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL));
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
   // (the SSE=OFF arithmetic keeps the byte image: its 32-test codes need the candidate BYTES in the matchers, wide_codes())
@@ -639,13 +663,31 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   const int tiles_y = (H - 2 * GPC_R + ty - 1) / ty;
   int tpw = 1;
   if ((long)gx * tiles_y * nimg >= 2l * slots) {  // small launches keep one tile per workgroup (parallelism first)
+    // What a split costs is the longest chain of tiles one of the `slots` resident workgroup places works through.  A column
+    // of tiles_y tiles becomes ceil(tiles_y / t) workgroups of t tiles and one of the remainder; the hardware starts the
+    // next workgroup wherever one ends, so the places fill like bins: as many whole workgroups as fit the rounds, the
+    // short ones last.  (Scored as "idle tail of the last round + 4 % for a ragged split" before: at 32 pairs of 1024x436
+    // -- 13 tile rows, 256 columns -- that took 4 + 4 + 4 + 1 tiles in two rounds (8 tiles on the longest chain) over
+    // 7 + 6 in one (7): k_hash 58 -> 52 us.)  A workgroup's start (tap tables, first window not overlapped) is ~0.4 tile.
     double best = 1e30;
     for (int t = 2; t <= 16 && t <= tiles_y; ++t) {
-      const long nwg = (long)gx * ((tiles_y + t - 1) / t) * nimg;
+      const long per_col = (tiles_y + t - 1) / t, ncol = (long)gx * nimg;
+      const long nwg = per_col * ncol;
       if (nwg < slots) break;
-      const long rounded = (nwg + slots - 1) / slots * slots;
-      const double score = (double)(rounded - nwg) / (double)rounded + ((tiles_y % t) ? 0.04 : 0.0);  // idle tail + ragged split
-      if (score < best - 1e-9) { best = score; tpw = t; }
+      const int rem = tiles_y - (int)(per_col - 1) * t;             // tiles of a column's last workgroup (1 .. t)
+      const long n_full = (per_col - 1) * ncol, n_rem = ncol;         // workgroups of t tiles / of rem tiles
+      // full-size workgroups dealt over the places first, the short ones onto the least loaded places
+      const long full_rounds = n_full / slots, full_left = n_full % slots;
+      double chain = (double)full_rounds * (t + 0.4);
+      long short_left = n_rem;
+      if (full_left) {  // `full_left` places carry one more full workgroup; the others take short ones meanwhile
+        const long free_places = slots - full_left;
+        const long fit = free_places * (long)((t + 0.4) / (rem + 0.4));  // short workgroups that fit beside that round
+        short_left = n_rem > fit ? n_rem - fit : 0;
+        chain += t + 0.4;
+      }
+      chain += (double)((short_left + slots - 1) / slots) * (rem + 0.4);
+      if (chain < best - 1e-9) { best = chain; tpw = t; }
     }
   }
   if (c->hash_tpw > 0) tpw = c->hash_tpw < tiles_y ? c->hash_tpw : tiles_y;  // GPC_HIP_HASH_TPW (tuning)
@@ -1605,6 +1647,35 @@ int dev_copy16(gpc_hip_ctx* c, void* dst, const void* src, size_t bytes) {
 
 inline size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// The chunk pipeline is a few hundred HIP calls and event waits per batch: driven from a CPU of the OTHER socket every
+// one of them crosses the inter-socket link on its way to the GPU, and the same 256-pair call takes 7.9 ms instead of
+// 5.3 (profiles/r05_c_h2h_numa.txt; which socket a process's main thread lands on is the scheduler's choice, which is
+// why one leg of the round-3 and round-4 bench records was slow and the other not).  So when the calling thread runs
+// off the GPU's NUMA node -- and the process may use that node's CPUs -- the pipeline runs on a thread of its own, bound
+// there like the expansion workers, and the caller waits for it.  The caller's own affinity is never touched.
+template <class F>
+int on_gpu_node(gpc_hip_ctx* c, int npairs, F&& body) {
+  bool hop = c && !c->no_feeder && c->have_node_cpus && npairs >= 4;
+  if (hop) {
+    // ... or is held on one or two CPUs (a pinned worker of the caller's own pool): the runtime's helper threads are
+    // created by whoever makes the first call, inherit that mask and then share the CPU with the pipeline -- the same
+    // call took 9.8 ms from a thread pinned to one CPU of the GPU's own node
+    const int cpu = sched_getcpu();
+    cpu_set_t cur;
+    const bool narrow = sched_getaffinity(0, sizeof cur, &cur) == 0 && CPU_COUNT(&cur) < 3 && CPU_COUNT(&c->node_cpus) >= 4;
+    hop = narrow || (cpu >= 0 && cpu < CPU_SETSIZE && !CPU_ISSET(cpu, &c->node_cpus));
+  }
+  if (!hop) return body();
+  int st = GPC_E_HIP;
+  std::thread t([&] {
+    (void)sched_setaffinity(0, sizeof c->node_cpus, &c->node_cpus);
+    st = body();
+  });
+  t.join();
+  ++c->fed_calls;
+  return st;
+}
+
 int ensure_pool(gpc_hip_ctx* c) {
   if (c->pool.size() == 0) {
     int nt = c->expand_threads > 0 ? c->expand_threads : default_expand_threads();
@@ -1718,6 +1789,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (et && atoi(et) > 0 && atoi(et) <= 64) c->expand_threads = atoi(et);
   if (const char* e = getenv("GPC_HIP_UPLOAD")) c->upload_mode = atoi(e);
   c->no_grad_bits = getenv("GPC_HIP_NO_GRAD_BITS") != nullptr;
+  c->no_feeder = getenv("GPC_HIP_NO_FEEDER") != nullptr;
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
   if (const char* e = getenv("GPC_HIP_HASH_TALL")) c->hash_tall = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GPC_HIP_PRE_ROWS")) {
@@ -2601,9 +2673,11 @@ static int match_batch_direct(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
   return status;
 }
 
+int gpc_hip_fed_calls(const gpc_hip_ctx* c) { return c ? c->fed_calls : 0; }
+
 int gpc_hip_match_batch(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
                         const gpc_settings* s, gpc_support* out, int cap, int32_t* counts, int32_t* ncand) {
-  const int st = match_batch_packed(c, rawL, rawR, W, H, npairs, s, out, cap, counts, ncand);
+  const int st = on_gpu_node(c, npairs, [&] { return match_batch_packed(c, rawL, rawR, W, H, npairs, s, out, cap, counts, ncand); });
   if (c && st != GPC_OK && st != GPC_E_CAPACITY && st != GPC_E_INVALID) {
     // An error left the chunk pipeline half way: expansion jobs may still write into `out`, copies may still
     // target the staging slots.  Nothing of this call may be in flight when the caller gets its buffers back.
@@ -2624,6 +2698,8 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
                               const PackedHost* ph) {
   if (!c || !rawL || !rawR || (!out && !ph) || !counts || npairs <= 0 || cap <= 0) return GPC_E_INVALID;
   if (ph && (!ph->packed || !ph->rows)) return GPC_E_INVALID;
+  const double t_entry = host_ms();
+  c->stage_ms[0] = c->stage_ms[1] = c->stage_ms[2] = c->stage_ms[3] = 0.f;
   CHK(check_settings(s));
   if (!s->epipolar_mode || s->use_hashtable) {
     if (ph) return GPC_E_UNSUPPORTED;  // rows are the unit of the packed format: the epipolar sort-matcher's
@@ -2826,20 +2902,25 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     if (k >= 1) CHK(download(k - 1));
     if (k >= 2) CHK(expand(k - 2));
   }
+  HIPCHK(c, hipEventSynchronize(c->e_in[(nch - 1) & 3]));  // (queued long before the kernels that follow it: no wait is added)
+  c->stage_ms[0] = (float)(host_ms() - t_entry);
   CHK(download(nch - 1));
+  c->stage_ms[1] = (float)(host_ms() - t_entry);
   if (nch >= 2) CHK(expand(nch - 2));
   CHK(expand(nch - 1));
+  c->stage_ms[2] = (float)(host_ms() - t_entry);
   c->pool.wait_all();
   HIPCHK(c, hipStreamSynchronize(c->s_cnt));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   CHK(check_join_err(c));
+  c->stage_ms[3] = (float)(host_ms() - t_entry);
   return status;
 }
 
 int gpc_hip_match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t* rawR, int W, int H, int npairs,
                                const gpc_settings* s, uint32_t* packed, int cap, int32_t* rows, int32_t* counts, int32_t* ncand) {
   const PackedHost ph = {packed, rows};
-  const int st = match_batch_packed(c, rawL, rawR, W, H, npairs, s, nullptr, cap, counts, ncand, &ph);
+  const int st = on_gpu_node(c, npairs, [&] { return match_batch_packed(c, rawL, rawR, W, H, npairs, s, nullptr, cap, counts, ncand, &ph); });
   if (c && st != GPC_OK && st != GPC_E_CAPACITY && st != GPC_E_INVALID && st != GPC_E_UNSUPPORTED) {
     c->pool.wait_all();   // (as in gpc_hip_match_batch: nothing of a failed call may still be in flight)
     if (c->s_in) {
@@ -2853,6 +2934,17 @@ int gpc_hip_match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_
 }
 
 int gpc_hip_host_threads(const gpc_hip_ctx* c) { return c ? c->pool.size() : 0; }
+
+int gpc_hip_batch_stages(const gpc_hip_ctx* c, float* ms4) {
+  if (!c || !ms4) return GPC_E_INVALID;
+  for (int i = 0; i < 4; ++i) ms4[i] = c->stage_ms[i];
+  return GPC_OK;
+}
+
+int gpc_hip_host_worker_cpus(gpc_hip_ctx* c, int* cpus, int cap) {
+  if (!c || (cap > 0 && !cpus) || cap < 0) return 0;
+  return c->pool.worker_cpus(cpus, cap);
+}
 int gpc_hip_host_numa_node(const gpc_hip_ctx* c) { return (c && c->have_node_cpus) ? c->numa_node : -1; }
 
 // The whole timed region of samples/sparsematch.cpp:45-52 for one pair, queued: images through the arena (or read where

@@ -216,3 +216,12 @@ def test_bench_gpus_2_plainly_starts_two_ranks():
     assert "without torch" in hh["measured_in"] and hh["value"] > 100
     assert line["pcie_inclusive"]["ranks"] == 2 and line["speedup_vs_cpu_1thread"] > 1
     assert "pipeline_frac" not in line["roofline"] and 0 < line["roofline"]["frac"] <= 1
+    # the strong-scaling leg (BASELINE configs[3] as written: 256 / N pairs per rank -- here cut to the 16 this run holds)
+    sg = line["strong_256"]
+    assert sg["pairs_per_rank_per_step"] == 16 and sg["pairs_per_step"] == 32 and sg["value"] > 1000
+    assert 0 < sg["efficiency_vs_n_times_one_gpu_256_pairs"] < 4
+    # where the host-to-host call's time goes: the stage clock of the expanded and of the packed call (rank 0's child)
+    stg = line["pcie_inclusive"]["stages"]
+    for leg in ("expanded", "packed"):
+        assert 0 < stg[leg]["upload_done"] <= stg[leg]["kernels_done"] <= stg[leg]["last_chunk_landed"] <= stg[leg]["delivered"]
+    assert "out" in line["pcie_inclusive"]["pages_on_node_rank0"]

@@ -12,6 +12,7 @@ import numpy as np  # noqa: E402
 
 import opengpc_amd as g  # noqa: E402
 from opengpc_amd.synth import synth_batch  # noqa: E402
+from opengpc_amd.hostinfo import cpu_nodes, current_cpu, pages_nodes, stage_summary  # noqa: E402
 
 
 def one(B, W, H, forest):
@@ -77,6 +78,7 @@ def serve(B, W, H, forest, dev_index, warm=5):
     sys.stdout.write("ready\n")
     sys.stdout.flush()
     tt, tp = [], []
+    st_rows, sp_rows = [], []
     for line in sys.stdin:
         cmd = line.strip()
         if cmd == "go":
@@ -84,6 +86,7 @@ def serve(B, W, H, forest, dev_index, warm=5):
             o, counts, ncand, st = ctx.match_batch(Lp, Rp, s, cap, out=out)
             dt = time.perf_counter() - t0
             tt.append(dt)
+            st_rows.append(ctx.batch_stages())
             sys.stdout.write("%.9f\n" % dt)
             sys.stdout.flush()
         elif cmd == "gop":
@@ -91,6 +94,7 @@ def serve(B, W, H, forest, dev_index, warm=5):
             pk, prow, pcounts, pncand, pst = ctx.match_batch_packed(Lp, Rp, s, cap, packed=pk, rows=prow)
             dt = time.perf_counter() - t0
             tp.append(dt)
+            sp_rows.append(ctx.batch_stages())
             sys.stdout.write("%.9f\n" % dt)
             sys.stdout.flush()
         elif cmd == "done":
@@ -105,7 +109,9 @@ def serve(B, W, H, forest, dev_index, warm=5):
     for j in sorted(set((0, B // 2, B - 1))):
         ok = ok and np.array_equal(g.capi.expand_packed(pk[j], prow[j], int(counts[j])), o[j, : int(counts[j])])
     rec["packed"] = {"status": int(pst), "calls": len(tp), "identical_to_expanded": ok,
-                     "bytes_delivered": int(counts.sum()) * 4 + B * H * 4}
+                     "bytes_delivered": int(counts.sum()) * 4 + B * H * 4, "stages_ms": stage_summary(sp_rows)}
+    rec["stages_ms"] = stage_summary(st_rows)
+    rec["pages_on_node"] = {"out": pages_nodes(out), "images": pages_nodes(Lp), "packed_out": pages_nodes(pk)}
     if rank == 0 and not os.environ.get("GPC_BENCH_NO_SINGLE"):
         rec["single_pair_host_to_host"] = single_pair(ctx, W, H, s)
     sys.stdout.write(json.dumps(rec) + "\n")
@@ -129,6 +135,14 @@ def host_info(ctx):
         info["expand_threads"] = int(ctx.L.gpc_hip_host_threads(ctx.h))
         info["gpu_numa_node"] = int(ctx.L.gpc_hip_host_numa_node(ctx.h))
         info["workers_bound_to_gpu_node"] = info["gpu_numa_node"] >= 0
+        nodes = cpu_nodes()
+        cpus = ctx.worker_cpus()
+        info["worker_cpus"] = cpus
+        info["worker_nodes"] = sorted(set(nodes.get(c, -1) for c in cpus))
+        me = current_cpu()
+        info["calling_thread_cpu"] = me
+        info["calling_thread_node"] = nodes.get(me, -1)
+        info["numa_nodes"] = len(set(nodes.values()))
     except Exception:
         pass
     return info
