@@ -222,6 +222,18 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* ctx, const uint8_t* d_rawL, const ui
                                int width, int height, int npairs, const gpc_settings* settings,
                                gpc_support* d_out, int cap_per_pair, int32_t* d_counts,
                                int32_t* d_ncand);
+/* A STREAM of batches (the same context called again and again): with two lanes, consecutive gpc_hip_match_batch_device
+ * calls (epipolar sort-matcher) alternate between two sets of workspaces on two streams of the context's own, and batch
+ * k+1's preprocess and hash kernels run beside batch k's join (measured: 0.905 instead of 0.945 ms per 256 pairs).  In
+ * this mode
+ *   - a call's inputs are what the context's stream has produced when the call is made;
+ *   - a call's outputs are complete after gpc_hip_synchronize, or -- for a caller that waits on a stream of its own
+ *     (gpc_hip_set_stream) -- after that stream has passed gpc_hip_pipeline_join, which makes it wait for every call
+ *     queued so far;
+ *   - two calls are in flight at a time: consecutive calls need distinct output arrays.
+ * lanes = 1 (the default) is the strict form above: everything on the context's stream, call by call. */
+int gpc_hip_set_pipeline(gpc_hip_ctx* ctx, int lanes);
+int gpc_hip_pipeline_join(gpc_hip_ctx* ctx);
 /* Same from/to host memory (pinned or pageable), synchronous.  With the reference's sparsematch settings
  * (epipolar mode, sort matcher) the results cross PCIe packed (4 bytes per support, see below) and are expanded
  * into `out` by worker threads of the library while later chunks are still on the link: settings->num_threads > 1

@@ -74,7 +74,7 @@ SYMBOLS = [
     "gpc_hip_warmup", "gpc_hip_preprocess", "gpc_hip_preprocess_begin", "gpc_hip_preprocess_fetch", "gpc_hip_resident_hits",
     "gpc_hip_rectified_match_begin", "gpc_hip_stereo_match_begin", "gpc_hip_match_pair_begin", "gpc_hip_match_fetch",
     "gpc_hip_hash_codes", "gpc_hip_rectified_match", "gpc_hip_stereo_match",
-    "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_match_batch",
+    "gpc_hip_match_pair", "gpc_hip_match_batch_device", "gpc_hip_set_pipeline", "gpc_hip_pipeline_join", "gpc_hip_match_batch",
     "gpc_hip_match_batch_device_packed", "gpc_hip_match_batch_packed", "gpc_hip_expand_packed", "gpc_hip_host_threads", "gpc_hip_host_numa_node", "gpc_hip_batch_stages", "gpc_hip_host_worker_cpus", "gpc_hip_fed_calls",
     "gpc_hip_enable_kernel_timing", "gpc_hip_set_kernel_timing_mask", "gpc_hip_reset_kernel_timing", "gpc_hip_kernel_count",
     "gpc_hip_kernel_name", "gpc_hip_kernel_launch_name", "gpc_hip_kernel_time",
@@ -143,6 +143,8 @@ def load():
     L.gpc_hip_host_threads.argtypes = [C.c_void_p]
     L.gpc_hip_host_numa_node.argtypes = [C.c_void_p]
     L.gpc_hip_fed_calls.argtypes = [C.c_void_p]
+    L.gpc_hip_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+    L.gpc_hip_pipeline_join.argtypes = [C.c_void_p]
     L.gpc_hip_batch_stages.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.gpc_hip_host_worker_cpus.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.gpc_hip_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -441,6 +443,13 @@ class Context:
         self._ck(self.L.gpc_hip_match_batch_device(self.h, C.c_void_p(d_rawL), C.c_void_p(d_rawR), width, height,
                                                    npairs, C.byref(settings), C.c_void_p(d_out), cap_per_pair,
                                                    C.c_void_p(d_counts), C.c_void_p(d_ncand or 0)))
+
+    def set_pipeline(self, lanes):
+        """2: consecutive match_batch_device calls alternate between two lanes (gpc_hip_set_pipeline); 1: strict."""
+        self._ck(self.L.gpc_hip_set_pipeline(self.h, int(lanes)))
+
+    def pipeline_join(self):
+        self._ck(self.L.gpc_hip_pipeline_join(self.h))
 
     def match_batch_device_packed(self, d_rawL, d_rawR, width, height, npairs, settings, d_packed, cap_per_pair,
                                   d_rows, d_counts, d_ncand=0):

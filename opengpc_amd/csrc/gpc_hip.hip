@@ -182,6 +182,24 @@ struct gpc_hip_ctx {
   bool have_node_cpus = false;    // CPUs of the NUMA node this GPU hangs off (from sysfs), within the process's affinity mask
   cpu_set_t node_cpus;
   int numa_node = -1;
+  // Two lanes (gpc_hip_set_pipeline): consecutive device-resident batch calls alternate between two sets of workspaces on
+  // two streams of the context's own, wired with events so that batch k+1's k_preprocess and k_hash run beside batch k's
+  // join (which then takes one workgroup per CU less: a wave slot per SIMD stays free for them).  A lane is SWAPPED INTO
+  // the members below for the duration of a call (LaneScope), so every run_* function works on it unchanged.
+  struct Lane {
+    hipStream_t s = nullptr;
+    hipEvent_t e_in = nullptr, e_hash = nullptr, e_join = nullptr;
+    DevBuf smooth, grad, codes, stats, jstate, staged, rowcnt;
+    size_t jstate_granules = 0;
+    uint32_t join_epoch = 0;
+    bool grad_is_bits = false, used = false;
+  };
+  Lane lanes[2];
+  int pipeline = 1, next_lane = 0;
+  // experiment hooks (gpc_hip_debug_pipeline_events, tools/overlap_experiment.py; all null in the product): events the
+  // device-resident batch call waits for before k_preprocess / between k_preprocess and k_hash, and records after k_hash /
+  // after the join -- enough to let one batch's k_preprocess run beside the previous batch's join and nothing else
+  hipEvent_t dbg_wait_pre = nullptr, dbg_wait_hash = nullptr, dbg_rec_hash = nullptr, dbg_rec_join = nullptr;
   bool no_feeder = false;         // GPC_HIP_NO_FEEDER: the chunk pipeline always runs on the calling thread (A/B checks)
   int fed_calls = 0;              // batch calls that ran on a feeder thread (gpc_hip_fed_calls)
   int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
@@ -921,7 +939,8 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
       HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_, NT, lds));                           \
       if (per_cu < 1) per_cu = 1;                                                                               \
     }                                                                                                           \
-    long nwg = c->fuse_wgs > 0 ? c->fuse_wgs : (long)per_cu * c->num_cus;                                       \
+    /* (two lanes: one workgroup per CU less, the other lane's k_preprocess / k_hash need a wave slot per SIMD) */ \
+    long nwg = c->fuse_wgs > 0 ? c->fuse_wgs : (long)((c->pipeline > 1 && per_cu > 1) ? per_cu - 1 : per_cu) * c->num_cus; \
     if (nwg > (long)npairs * nrows) nwg = (long)npairs * nrows;                                                 \
     /* every shard needs a workgroup that draws its tickets (workgroup b serves shard b % nshards) */           \
     int nsh = join_shards(c, npairs);                                                                           \
@@ -1676,6 +1695,47 @@ int on_gpu_node(gpc_hip_ctx* c, int npairs, F&& body) {
   return st;
 }
 
+
+// Swaps a lane's workspaces, join state and stream into the context's members (and back): the pipeline stages then run on
+// the lane exactly as they run on the context.
+struct LaneScope {
+  gpc_hip_ctx* c;
+  gpc_hip_ctx::Lane& l;
+  hipStream_t user;
+  LaneScope(gpc_hip_ctx* ctx, gpc_hip_ctx::Lane& lane) : c(ctx), l(lane), user(ctx->stream) { swap(); c->stream = l.s; }
+  ~LaneScope() { swap(); c->stream = user; }
+  void swap() {
+    std::swap(c->smooth, l.smooth);
+    std::swap(c->grad, l.grad);
+    std::swap(c->codes, l.codes);
+    std::swap(c->stats, l.stats);
+    std::swap(c->jstate, l.jstate);
+    std::swap(c->staged, l.staged);
+    std::swap(c->rowcnt, l.rowcnt);
+    std::swap(c->jstate_granules, l.jstate_granules);
+    std::swap(c->join_epoch, l.join_epoch);
+    std::swap(c->grad_is_bits, l.grad_is_bits);
+  }
+};
+
+int ensure_lanes(gpc_hip_ctx* c) {
+  for (auto& l : c->lanes) {
+    if (l.s) continue;
+    HIPCHK(c, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&l.e_in, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&l.e_hash, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&l.e_join, hipEventDisableTiming));
+  }
+  return GPC_OK;
+}
+
+// every lane's queued work is done (host wait)
+int drain_lanes(gpc_hip_ctx* c) {
+  for (auto& l : c->lanes)
+    if (l.s && l.used) HIPCHK(c, hipStreamSynchronize(l.s));
+  return GPC_OK;
+}
+
 int ensure_pool(gpc_hip_ctx* c) {
   if (c->pool.size() == 0) {
     int nt = c->expand_threads > 0 ? c->expand_threads : default_expand_threads();
@@ -1835,6 +1895,7 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
       if (g_ctxs[k] == c) { g_ctxs.erase(g_ctxs.begin() + k); break; }
   }
   (void)hipSetDevice(c->device);
+  (void)drain_lanes(c);
   (void)hipStreamSynchronize(c->stream);
   // a fused-join time-out nobody has asked about (callers that only ever waited on their own stream): say so, once
   const int pending_err = check_join_err(c);
@@ -1861,6 +1922,17 @@ int gpc_hip_destroy(gpc_hip_ctx* c) {
   }
   if (c->e_flag) (void)hipEventDestroy(c->e_flag);
   if (c->e_pre) (void)hipEventDestroy(c->e_pre);
+  for (auto& l : c->lanes) {
+    if (l.s) {
+      (void)hipStreamSynchronize(l.s);
+      (void)hipStreamDestroy(l.s);
+      (void)hipEventDestroy(l.e_in);
+      (void)hipEventDestroy(l.e_hash);
+      (void)hipEventDestroy(l.e_join);
+    }
+    DevBuf* lb[] = {&l.smooth, &l.grad, &l.codes, &l.stats, &l.jstate, &l.staged, &l.rowcnt};
+    for (DevBuf* b : lb) release(*b);
+  }
   if (c->s_aux) {
     (void)hipStreamDestroy(c->s_aux);
     (void)hipEventDestroy(c->e_fork);
@@ -1889,6 +1961,7 @@ int gpc_hip_set_stream(gpc_hip_ctx* c, void* hip_stream) {
 
 int gpc_hip_synchronize(gpc_hip_ctx* c) {
   if (!c) return GPC_E_INVALID;
+  CHK(drain_lanes(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return check_join_err(c);
 }
@@ -2038,6 +2111,7 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
   c->forest_naive = fn;
   HIPCHK(c, hipSetDevice(c->device));
   CHK(ensure(c, c->forest_dev, 3 * sizeof(GpcForestDev)));
+  CHK(drain_lanes(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // a launch in flight may still read the previous tests
   const GpcForestDev both[3] = {f, fn, ft};
   HIPCHK(c, hipMemcpy(c->forest_dev.p, both, sizeof both, hipMemcpyHostToDevice));
@@ -2402,11 +2476,66 @@ int gpc_hip_match_batch_device(gpc_hip_ctx* c, const uint8_t* d_rawL, const uint
   CHK(forest_matches(c, W, H));
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)W * H;
+  if (c->pipeline > 1 && s->epipolar_mode && !s->use_hashtable) {
+    // Two lanes: this call goes to the lane the previous one did not take.  Its inputs are what the context's stream has
+    // produced so far (e_in); its k_preprocess starts when the other lane's k_hash is done -- beside that lane's join --
+    // and its join is queued behind its own k_hash only: the other lane's join is draining by then and this one's
+    // workgroups move in as places fall free.  Nothing is queued on the context's stream: gpc_hip_synchronize (or
+    // gpc_hip_pipeline_join for a caller with a stream of its own) orders the results.
+    CHK(ensure_lanes(c));
+    gpc_hip_ctx::Lane& lane = c->lanes[c->next_lane];
+    gpc_hip_ctx::Lane& other = c->lanes[c->next_lane ^ 1];
+    c->next_lane ^= 1;
+    HIPCHK(c, hipEventRecord(lane.e_in, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(lane.s, lane.e_in, 0));
+    if (other.used) HIPCHK(c, hipStreamWaitEvent(lane.s, other.e_hash, 0));
+    LaneScope in(c, lane);
+    lane.used = true;
+    CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
+    CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold, true));
+    CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false, (uint32_t*)c->codes.p));
+    HIPCHK(c, hipEventRecord(lane.e_hash, c->stream));
+    CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out, cap_per_pair, d_counts, d_ncand));
+    HIPCHK(c, hipEventRecord(lane.e_join, c->stream));
+    return GPC_OK;
+  }
+  if (c->pipeline > 1) CHK(drain_lanes(c));  // (the device-wide matchers run on the context itself)
   CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2 * npairs));
+  if (c->dbg_wait_pre) HIPCHK(c, hipStreamWaitEvent(c->stream, c->dbg_wait_pre, 0));
   CHK(run_preprocess(c, d_rawL, d_rawR, W, H, npairs, 2, s->gradient_threshold, true));
+  if (c->dbg_wait_hash) HIPCHK(c, hipStreamWaitEvent(c->stream, c->dbg_wait_hash, 0));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2 * npairs, false,
                (uint32_t*)c->codes.p));
+  if (c->dbg_rec_hash) HIPCHK(c, hipEventRecord(c->dbg_rec_hash, c->stream));
   CHK(run_match(c, W, H, npairs, s, 0, (const uint8_t*)c->grad.p, d_out, cap_per_pair, d_counts, d_ncand));
+  if (c->dbg_rec_join) HIPCHK(c, hipEventRecord(c->dbg_rec_join, c->stream));
+  return GPC_OK;
+}
+
+// Experiment hook, not part of the C ABI (include/gpc_hip.h does not declare it): see gpc_hip_ctx::dbg_wait_pre.
+int gpc_hip_set_pipeline(gpc_hip_ctx* c, int lanes) {
+  if (!c || (lanes != 1 && lanes != 2)) return GPC_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(drain_lanes(c));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->pipeline = lanes;
+  return GPC_OK;
+}
+
+int gpc_hip_pipeline_join(gpc_hip_ctx* c) {
+  if (!c) return GPC_E_INVALID;
+  for (auto& l : c->lanes)
+    if (l.s && l.used) HIPCHK(c, hipStreamWaitEvent(c->stream, l.e_join, 0));
+  return GPC_OK;
+}
+
+int gpc_hip_debug_pipeline_events(gpc_hip_ctx* c, void* wait_before_preprocess, void* wait_before_hash, void* record_after_hash,
+                                  void* record_after_join) {
+  if (!c) return GPC_E_INVALID;
+  c->dbg_wait_pre = (hipEvent_t)wait_before_preprocess;
+  c->dbg_wait_hash = (hipEvent_t)wait_before_hash;
+  c->dbg_rec_hash = (hipEvent_t)record_after_hash;
+  c->dbg_rec_join = (hipEvent_t)record_after_join;
   return GPC_OK;
 }
 
@@ -3409,6 +3538,7 @@ int gpc_hip_set_kernel_timing_mask(gpc_hip_ctx* c, unsigned mask) {
 
 int gpc_hip_reset_kernel_timing(gpc_hip_ctx* c) {
   if (!c) return GPC_E_INVALID;
+  CHK(drain_lanes(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& s : c->spans) c->free_spans.push_back(s);
   c->spans.clear();
@@ -3427,6 +3557,7 @@ const char* gpc_hip_kernel_launch_name(const gpc_hip_ctx* c, int index) {
 
 int gpc_hip_kernel_time(gpc_hip_ctx* c, int index, float* total_ms, int* launches) {
   if (!c || index < 0 || index >= KID_COUNT) return GPC_E_INVALID;
+  CHK(drain_lanes(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float tot = 0.f;
   int cnt = 0;

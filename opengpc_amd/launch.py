@@ -7,6 +7,7 @@ devices in a throw-away child, exports what torch.distributed.run would export, 
 and stops the others by exact PID when one fails.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -57,18 +58,64 @@ def launch_local_ranks(n, cmd, backend="nccl", count_devices=visible_devices, po
               "(GPC_DIST_BACKEND=gloo rehearses the N-rank line with the ranks sharing the devices there are)" % (n, ndev), file=log)
         return 2
     port = os.environ.get("MASTER_PORT") or free_port()
-    procs = [subprocess.Popen(list(cmd), env=rank_env(n, r, port), stdout=None if r == 0 else log) for r in range(n)]
-    rc, alive = 0, set(range(n))
-    while alive:
-        for r in sorted(alive):
-            st = procs[r].poll()
-            if st is None:
-                continue
-            alive.discard(r)
-            if st != 0 and rc == 0:
-                rc = st if st > 0 else 128 - st
-                print("launch: rank %d exited with status %d; stopping the other ranks" % (r, st), file=log)
+    # Every rank in a session (process group) of its own: a rank's children (bench.py's host-to-host child) are reached by
+    # the group's signal too.  SIGTERM / SIGINT to THIS process (a driver's `timeout`) are forwarded to the groups, so no
+    # rank is left holding a GPU; a rank that ignores SIGTERM is killed after `grace_s`.  Exact process groups started
+    # here, never a pattern.
+    procs = [subprocess.Popen(list(cmd), env=rank_env(n, r, port), stdout=None if r == 0 else log, start_new_session=True)
+             for r in range(n)]
+    grace_s = float(os.environ.get("GPC_LAUNCH_GRACE_S", "10"))
+
+    def signal_group(p, sig):
+        try:
+            os.killpg(p.pid, sig)       # (start_new_session: the rank's pid is its group's id)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                signal_group(p, sig)
+
+    got = []
+
+    def on_signal(signum, frame):
+        got.append(signum)
+        stop_all(signal.SIGTERM)
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:              # not the main thread (tests): no forwarding, the finally below still cleans up
+            pass
+    rc, alive, deadline = 0, set(range(n)), None
+    try:
+        while alive:
+            for r in sorted(alive):
+                st = procs[r].poll()
+                if st is None:
+                    continue
+                alive.discard(r)
+                if st != 0 and rc == 0:
+                    rc = st if st > 0 else 128 - st
+                    print("launch: rank %d exited with status %d; stopping the other ranks" % (r, st), file=log)
+                    for q in alive:
+                        signal_group(procs[q], signal.SIGTERM)
+                    deadline = time.monotonic() + grace_s
+            if got and deadline is None:
+                deadline = time.monotonic() + grace_s
+            if deadline is not None and time.monotonic() > deadline:
                 for q in alive:
-                    procs[q].terminate()
-        time.sleep(poll_s)
+                    print("launch: rank %d did not stop within %.0f s: killed" % (q, grace_s), file=log)
+                    signal_group(procs[q], signal.SIGKILL)
+                deadline = time.monotonic() + 3600.0
+            time.sleep(poll_s)
+    finally:
+        for p in procs:                 # whatever ends this function, no rank outlives it
+            if p.poll() is None:
+                signal_group(p, signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if got and rc == 0:
+        rc = 128 + got[0]
     return rc

@@ -609,3 +609,51 @@ def test_fused_join_equals_the_two_launch_path(oracle, forest_paths):
     finally:
         one.close()
         two.close()
+
+
+def test_two_lane_pipeline_equals_the_strict_form(forest_paths):
+    """gpc_hip_set_pipeline(2): consecutive device-resident batches alternate between two lanes, batch k+1's preprocess and
+    hash kernels run beside batch k's join.  Six batches of different pairs: every support of every pair equals the strict
+    (one stream, call by call) result; a caller's own stream orders the results through gpc_hip_pipeline_join."""
+    import torch
+    import opengpc_amd as g
+    from opengpc_amd.synth import synth_batch
+    W, H, B, NB = 1024, 436, 24, 6
+    dev = torch.device("cuda", 0)
+    cap = 300000
+    s = g.Settings.sparsematch()
+    batches = []
+    for k in range(NB):
+        L, R = synth_batch(W, H, [100 * k + j for j in range(B)])
+        batches.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
+
+    def run(lanes, own_stream):
+        c = g.Context(0)
+        try:
+            st = torch.cuda.Stream(device=dev) if own_stream else None
+            if st is not None:
+                c.set_stream(st.cuda_stream)
+            c.load_forest(forest_paths["zero"], W, H)
+            c.set_pipeline(lanes)
+            outs = [(torch.zeros((B, cap, 3), dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+                     torch.zeros((B, 2), dtype=torch.int32, device=dev)) for _ in range(NB)]
+            for rep in range(3):       # (the lanes' first calls allocate: later rounds run with everything in place)
+                for k, (dl, dr) in enumerate(batches):
+                    o, n, nc = outs[k]
+                    c.match_batch_device(dl.data_ptr(), dr.data_ptr(), W, H, B, s, o.data_ptr(), cap, n.data_ptr(), nc.data_ptr())
+            if st is not None:
+                c.pipeline_join()      # the caller's stream now waits for every call queued so far
+                st.synchronize()
+                assert c.L.gpc_hip_synchronize(c.h) == 0
+            else:
+                c.synchronize()
+            return [(o.cpu().numpy(), n.cpu().numpy(), nc.cpu().numpy()) for o, n, nc in outs]
+        finally:
+            c.close()
+
+    want = run(1, False)
+    for own in (False, True):
+        got = run(2, own)
+        for (wo, wn, wc), (go, gn, gc) in zip(want, got):
+            assert np.array_equal(wn, gn) and np.array_equal(wc, gc) and wn.min() > 1000
+            assert np.array_equal(wo, go)        # (zero-filled arrays: only valid records are ever written)

@@ -101,6 +101,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "fail" and r == 1:
 if len(sys.argv) > 1 and sys.argv[1] == "fail":
     import time
     time.sleep(60)          # the launcher must stop this rank when rank 1 fails
+if len(sys.argv) > 1 and sys.argv[1] == "hang":
+    import signal, subprocess, time
+    if r == 1:
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)     # a rank that does not stop when asked
+    kid = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])    # a rank's own child (bench.py's HostChild)
+    print("pids %d %d" % (os.getpid(), kid.pid), file=sys.stderr, flush=True)
+    time.sleep(300)
 print(json.dumps({"rank": r, "world": w}))
 """
 
@@ -142,6 +149,42 @@ def test_launcher_failing_rank_stops_the_job(tmp_path):
     r = run_launcher(tmp_path, 3, 8, "nccl", "fail")
     assert r.returncode == 7 and "rank 1 exited with status 7" in r.stderr
     assert time.time() - t0 < 30     # ranks 0 and 2 were stopped, not waited for
+
+
+def test_launcher_forwards_sigterm_and_leaves_nothing_behind(tmp_path):
+    """A driver's `timeout` sends SIGTERM to the launcher: every rank's process GROUP (the rank and its children) is told to
+    stop, a rank that ignores that is killed after the grace period, and the launcher returns 128 + 15."""
+    import signal
+    import time
+    prog = tmp_path / "rank_prog.py"
+    prog.write_text(RANK_PROG)
+    drv = ("import sys; sys.path.insert(0, %r)\n"
+           "from opengpc_amd.launch import launch_local_ranks\n"
+           "sys.exit(launch_local_ranks(2, [sys.executable, %r, 'hang'], backend='nccl', count_devices=lambda: 8))\n" % (ROOT, str(prog)))
+    env = dict(os.environ, GPC_LAUNCH_GRACE_S="2")
+    p = subprocess.Popen([sys.executable, "-c", drv], stderr=subprocess.PIPE, text=True, env=env)
+    pids = []
+    t0 = time.time()
+    while len(pids) < 4 and time.time() - t0 < 60:
+        line = p.stderr.readline()
+        if line.startswith("pids "):
+            pids += [int(v) for v in line.split()[1:]]
+    assert len(pids) == 4
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    rest = p.stderr.read()
+    assert rc == 128 + signal.SIGTERM, rest
+    assert "did not stop within" in rest               # rank 1 ignored SIGTERM and was killed
+    time.sleep(0.3)
+    for pid in pids:                                    # neither a rank nor a rank's child is left
+        alive = True
+        try:
+            os.kill(pid, 0)
+            with open("/proc/%d/stat" % pid) as fh:      # (a zombie waiting for its reaper does not hold anything)
+                alive = fh.read().split(") ")[1][0] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
 
 
 def test_bench_plainly_with_gpus_2_without_a_gpu_fails_loudly():

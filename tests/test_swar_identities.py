@@ -65,9 +65,42 @@ def test_lerp_compare_polarities():
 
 
 def test_bitop3_tables():
-    """v_bitop3_b32 table index = a * 4 + b * 2 + c.  0xE4: c ? a : b.  0x4E: c ? ~a : b."""
-    for tt, f in ((0xE4, lambda a, b, c: a if c else b), (0x4E, lambda a, b, c: (1 - a) if c else b)):
+    """v_bitop3_b32 table index = a * 4 + b * 2 + c.  The plane inserts -- 0xE4: c ? a : b; 0x4E: c ? ~a : b -- and the
+    store phase of the batched SSE instantiations (k_hash.h, INV: a = the complemented code, b = "row is hashed", c = the
+    candidate mask / the running OR): 0xAE: c | (~a & b); 0x5D: c ? (~a & b) : 1; 0xD5 (a = the plain code): c ? (a & b) : 1."""
+    tables = (
+        (0xE4, lambda a, b, c: a if c else b),
+        (0x4E, lambda a, b, c: (1 - a) if c else b),
+        (0xAE, lambda a, b, c: c | ((1 - a) & b)),
+        (0x5D, lambda a, b, c: ((1 - a) & b) if c else 1),
+        (0xD5, lambda a, b, c: (a & b) if c else 1),
+    )
+    for tt, f in tables:
         for a in (0, 1):
             for b in (0, 1):
                 for c in (0, 1):
-                    assert (tt >> (a * 4 + b * 2 + c)) & 1 == f(a, b, c)
+                    assert (tt >> (a * 4 + b * 2 + c)) & 1 == f(a, b, c), hex(tt)
+
+
+def test_complemented_plane_forms_of_the_transpose():
+    """k_hash keeps the planes as NOT(code bit) and, in the batched SSE instantiations (INV), the codes complemented through
+    the byte transposes.  The complemented forms of the two planes that are not plain complements:
+        q0:  ~(~p0 | ((~p8 >> 7) & m8))  ==  p0 & ((p8 >> 7) | ~m8)           (test 8 OR-ed into bit 0 where m8 selects)
+        q3:  ~((~p3 >> s) & m3)          ==  (p3 >> s) | ~m3                   (the last plane's n3 = 8 - s tests)
+    for every 32-bit word, both m8 values and every n3 (numpy, random words + the corner words)."""
+    rng = np.random.default_rng(5)
+    words = np.concatenate([rng.integers(0, 1 << 32, 20000, dtype=np.uint64), np.array([0, 0xFFFFFFFF, 0x80808080, 0x7F7F7F7F, 0x01010101], np.uint64)])
+    M = np.uint64(0xFFFFFFFF)
+    p0, p8, p3 = words, np.roll(words, 7), np.roll(words, 13)
+    for m8 in (np.uint64(0x01010101), np.uint64(0x01010100)):
+        plain = (~p0 & M) | (((~p8 & M) >> np.uint64(7)) & m8)
+        inv = p0 & ((p8 >> np.uint64(7)) | (~m8 & M))
+        assert np.array_equal(~plain & M, inv)
+    for n3 in range(1, 8):
+        m3 = np.uint64(0x01010101 * ((1 << n3) - 1))
+        s = np.uint64(8 - n3)
+        plain = ((~p3 & M) >> s) & m3
+        inv = (p3 >> s) | (~m3 & M)
+        # the shift drags bits of the neighbouring byte in; only the bits m3 selects are code bits -- the others are
+        # all-ones in the complemented form (code bit 0) and zero in the plain one
+        assert np.array_equal(~plain & M, inv)
