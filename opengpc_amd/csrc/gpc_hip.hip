@@ -249,7 +249,6 @@ struct gpc_hip_ctx {
   std::map<const void*, int> dyn_lds;     // largest dynamic-LDS size a kernel has been allowed so far (hipFuncSetAttribute once, not per call)
 
   int hash_tpw = 0;    // GPC_HIP_HASH_TPW: tiles per workgroup of the hash kernel (tuning)
-  int join_rpw = 0;    // GPC_HIP_JOIN_RPW: rows per workgroup of the join kernel (tuning)
   int join_nt = 0;     // GPC_HIP_JOIN_NT = 256 | 512 | 1024: force the join kernel's threads per row (tuning)
 
   // rocprof name of the instantiation last launched under each timing slot (bench.py reports it)
@@ -975,7 +974,7 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
     }
     {
       Timed t(c, KID_ROW_JOIN);
-      const int rpw = 1;  // (GPC_HIP_JOIN_RPW is accepted and ignored: the kernel takes one row per workgroup)
+      const int rpw = 1;  // (the kernel takes one row per workgroup)
       const dim3 jgrid((H - 2 * GPC_R + rpw - 1) / rpw, npairs);
       const bool wide = wide_codes(c);
       snprintf(c->launch_name[KID_ROW_JOIN], sizeof c->launch_name[0], "gpc::k_row_join<%d, %d, %s>", jp.spt, jp.nt,
@@ -1814,8 +1813,6 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   c->stream = c->own_stream;
   const char* ht = getenv("GPC_HIP_HASH_TPW");
   if (ht && atoi(ht) > 0 && atoi(ht) <= 64) c->hash_tpw = atoi(ht);
-  const char* jr = getenv("GPC_HIP_JOIN_RPW");
-  if (jr && atoi(jr) > 0 && atoi(jr) <= 64) c->join_rpw = atoi(jr);
   c->no_partition = getenv("GPC_HIP_NO_PARTITION") != nullptr;
   c->flat_chunks = getenv("GPC_HIP_FLAT_CHUNKS") != nullptr;
   if (const char* e = getenv("GPC_HIP_GP_TARGET")) {
