@@ -194,7 +194,7 @@ def cpu_baseline(args, W, H):
 
 
 def compulsory_bytes(W, H, B, M_step, fused=True):
-    """HBM bytes each kernel must move per launch given its input / output formats (DESIGN.md 3):
+    """HBM bytes each kernel must move per launch given its input / output formats (DESIGN.md 4):
     what the roofline of that kernel is priced on.  M = supports of the step.  `fused`: the join writes the 12-byte
     supports itself (one launch); otherwise it stages 4-byte words and k_gather_rows expands them."""
     rows = H - 26
@@ -403,7 +403,7 @@ def main():
             gdist.timed_calls(child_call, host_reps)   # barrier before each repetition; the child times its own call
             host_times = res_t
             # and the packed variant of the same call (gpc_hip_match_batch_packed: the records stay 4 bytes each in host
-            # memory -- what a node of 8 ranks has the memory bandwidth for, DESIGN.md 5)
+            # memory -- what a node of 8 ranks has the memory bandwidth for, DESIGN.md 7)
             gdist.timed_calls(lambda: packed_times.append(child.call("gop")), packed_reps)
             child_rec = child.finish()
         finally:
@@ -532,7 +532,7 @@ def main():
             "pipeline_alg_bytes_per_pair": a_pair,
             "pipeline_alg_GBs_equivalent": round(a_pair * pairs_per_step * args.steps / t_med / 1e9, 1),
             "pipeline_compulsory_frac": round(sum(alg.values()) * world * args.steps / t_med / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "achieved = bytes the dominant kernel must read + write per launch given its formats (DESIGN.md 3: "
+            "note": "achieved = bytes the dominant kernel must read + write per launch given its formats (DESIGN.md 4: "
                     "%s) / mean HIP-event duration of its %d launches inside the timed windows, on the stream it runs on.  "
                     "The kernel keeps the reference's sort in LDS and is bound by LDS / issue, not by HBM: `frac` says how "
                     "far below the HBM roof that leaves it.  `traffic` is not measured by this script; "

@@ -277,7 +277,7 @@ int gpc_hip_match_batch_device_packed(gpc_hip_ctx* ctx, const uint8_t* d_rawL, c
  * first cap_per_pair records are delivered).  For callers that consume supports row by row, or that expand them later /
  * elsewhere with gpc_hip_expand_packed: a batch of 256 pairs of 1024x436 leaves 209 MB in host memory where the
  * ndb::Support arrays of gpc_hip_match_batch are 625 MB -- with one process per GPU on an 8-GPU node those 12-byte records
- * are what the host's memory bandwidth runs out on (DESIGN.md 5).  Epipolar sort-matcher only (GPC_E_UNSUPPORTED otherwise). */
+ * are what the host's memory bandwidth runs out on (DESIGN.md 7).  Epipolar sort-matcher only (GPC_E_UNSUPPORTED otherwise). */
 int gpc_hip_match_batch_packed(gpc_hip_ctx* ctx, const uint8_t* rawL, const uint8_t* rawR, int width, int height,
                                int npairs, const gpc_settings* settings, uint32_t* packed, int cap_per_pair,
                                int32_t* rows, int32_t* counts, int32_t* ncand);

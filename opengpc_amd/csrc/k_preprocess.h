@@ -177,7 +177,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
   const bool strip_first = x0 == 0, strip_last = x0 + PP_PX == W;
   const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw), 0, (int)n, 0x00020000);
   PreRow rows[3];
-#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
+#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth, docs/HISTORY.md 7)
 #ifndef PP_DEPTH
 #define PP_DEPTH 2   // rows requested ahead of the one being unpacked
 #endif
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(PP_TX * PP_TY) PP_OCC void k_preprocess(
     PreRow& up = rows[i % 3];
     PreRow& mid = rows[(i + 1) % 3];
     PreRow& dn = rows[(i + 2) % 3];
-#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth)
+#if PP_PX == 8 && defined(PP_PREFETCH)  // (experiment: measured slower at every depth, docs/HISTORY.md 7)
     if (i + 2 + PD < ROWS + 2) rv[i + 2 + PD] = pre_fetch_row(raw, (int)n, W, H, ys + 1 + i + PD, x0);
     asm volatile("" ::: "memory");  // (keeps the requests where they are: hoisted to the top they cost the kernel its occupancy)
     pre_unpack_row<NAIVE>(rv[i + 2], dn);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RjOcc<SPT, N
     const int32_t* __restrict__ img_stats, uint32_t* __restrict__ staged, int32_t* __restrict__ rowcnt,
     int log2s, int rpw, RjVirt v) {
 #ifndef RJ_KEEP_RPW
-  rpw = 1;  // (rows per workgroup with next-row prefetch measured within the noise of one row, DESIGN.md 7, and its eight
+  rpw = 1;  // (rows per workgroup with next-row prefetch measured within the noise of one row, docs/HISTORY.md 7, and its eight
             // prefetch registers put scratch into the 1024-thread instantiation: one row per workgroup it is)
 #endif
   // flags of a table slot (one word per slot, x of a right record in the low half)

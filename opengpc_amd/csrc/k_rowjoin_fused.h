@@ -23,7 +23,7 @@
 //     row put that wait on every row's critical path.  So row n asks for its predecessors' granules after row n+1's
 //     insert phase, looks at the answer after row n+1's lookup phase and writes row n's records while row n+1 ranks.
 //
-// Round 4: a kernel of its own (it was the FUSE instantiation of k_row_join).  What binds it ("what binds
+// Round 4: a kernel of its own (it was the FUSE instantiation of k_row_join).  What binds it (docs/HISTORY.md 3, "what binds
 // the fused join"): the ~11 us a row spends inside its workgroup times the eight rows a CU holds -- all 32 wave slots and all
 // 160 KB of LDS -- not instruction count, LDS throughput, HBM latency or barriers (each was varied by itself).  What changed:
 //   * ONE by-value parameter (RjfArgs).  What every wave needs on its critical path (W, H, code image, statistics, filter

@@ -2,7 +2,7 @@
 hot-path kernels, held by the compiler's own resource report (tools/kres.sh = hipcc -Rpass-analysis=kernel-resource-usage).
 
 A kernel that spills VECTOR registers goes to scratch memory, and a scratch reload waits for every vector-memory
-operation its wave has in flight: no instantiation a BASELINE configuration can reach may do that.
+operation its wave has in flight (docs/HISTORY.md 3): no instantiation a BASELINE configuration can reach may do that.
 Scalar registers spilled to VGPR lanes are cheap (a v_readlane) and are only bounded, not forbidden."""
 import os
 import re

@@ -46,7 +46,7 @@ def main():
     must["k_row_join_fused"] = must["k_row_join"]
     out = {"_comment": "rocprofv3 --kernel-trace --stats averages and --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of "
                        "tools/prof_step.py %s; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction); "
-                       "must_move = bytes the kernel has to read + write given its input / output formats (DESIGN.md 3)"
+                       "must_move = bytes the kernel has to read + write given its input / output formats (DESIGN.md 4)"
                        % " ".join(sys.argv[2:]),
            "config": {"pairs_per_launch": B, "width": W, "height": H, "forest": forest, "steps": steps,
                       "candidates_per_pair": cand, "supports_per_pair": supports},
