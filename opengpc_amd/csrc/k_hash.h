@@ -419,12 +419,15 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
     }
   };
 
+  constexpr bool INV = !DENSE && !NAIVE;
+  constexpr int CBIT = GBITS ? 0 : 7;   // where cand8 keeps a pixel's candidate flag inside its byte
   const int tile0 = by * tpw;
   const int ntiles = (H - 2 * GPC_R + TY - 1) / TY;
   HT_STAMP_INIT();
   fetch(GPC_R + tile0 * TY);
   int cnt = 0, last = -1;
   uint32_t cor = 0u;  // OR of the codes computed here (candidates or not: a superset costs the join nothing)
+  uint32_t cor3 = 0u; // INV: OR of the last plane's complemented bytes (the codes' bits 24 .. 30), folded into cor at the end
   const int T = fp->num_tests;
   int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
   // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
@@ -463,8 +466,11 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
     for (int r = 0; r < RPW; ++r) {
       const int y = yw + r;
       const uint32_t g4 = gq[r];
-      const uint32_t nib = (g4 >> (x0 & 15)) & 0xFu;
-      const uint32_t cb = (nib * 0x10204080u) & SW_H & xmask & (y < H - GPC_R ? ~0u : 0u);
+      // own nibble -> BIT 0 of byte j (CBIT): nib * 0x204081 puts bit k of the nibble at 7j + k for j = 0 .. 3, i.e. bit j at
+      // bit 0 of byte j (the other products fall on bits 1 .. 3 and are masked with the margin mask) -- a 24-bit multiply at
+      // full rate where nib * 0x10204080 (bit 7 of byte j) was a v_mul_lo_u32 at a quarter of it
+      const uint32_t nib = __builtin_amdgcn_ubfe(g4, (uint32_t)(x0 & 15), 4u);
+      const uint32_t cb = __umul24(nib, 0x204081u) & (xmask >> 7) & (y < H - GPC_R ? ~0u : 0u);
       cand8[r] = cb;
       rowdo[r] = (y < H - 15) & (g4 != 0u);  // gpcFilterSegment(13, height-15) :602; groups without a gradient byte are skipped :566
       any = any | ((cb != 0u) & rowdo[r]);
@@ -498,9 +504,8 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 
   // ---- the tests, in the reference's byte planes: P0 = tests 0..7, (test 8), P1 = 9..16,
   //      P2 = 17..24, P3 = 25..31.  Tests >= T are padded with equal taps (compare false).
-  // The planes hold NOT(code bit).  The batched SSE instantiations keep the codes complemented through the transposes and
-  // take the complement inside the store phase's v_bitop3 (a truth table costs nothing): four v_not per row less.
-  constexpr bool INV = !DENSE && !NAIVE;
+  // The planes hold NOT(code bit).  The batched SSE instantiations (INV) keep the codes complemented through the transposes
+  // and take the complement inside the store phase's v_bitop3 (a truth table costs nothing): four v_not per row less.
   uint32_t code[RPW][4];   // INV: the complemented codes
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
@@ -540,6 +545,11 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
       const uint32_t q2 = INV ? p2[r] : ~p2[r];
       // P3 saw n3 tests (first one now n3 - 1 places below bit 7): bring the first down to bit 0
       const uint32_t q3 = INV ? ((p3[r] >> (8 - n3)) | ~m3) : (NAIVE ? ~p3[r] : ((~p3[r] >> (8 - n3)) & m3));
+      // INV: the joins want the highest bit any code of the image has set (GPC_STAT_CODEOR: its leading zeros size their rank
+      // buckets).  Bits 24 .. 30 of a code are its pixel's byte of the last plane, so the OR of that plane's bytes over the
+      // rows that are hashed says which of them occur; below bit 24 the statistic is "every bit the forest can set" (a
+      // superset is all the joins need).  One operation per row: cor3 | (~q3 & do).
+      if (INV) cor3 = __builtin_amdgcn_bitop3_b32(q3, rowdo[r] ? ~0u : 0u, cor3, 0xAE);
       // transpose 4 planes x 4 pixels -> 4 codes (byte k of code j = plane k, byte j)
       const uint32_t lo01 = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
       const uint32_t hi01 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
@@ -575,9 +585,9 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
         const uint32_t dom = rowdo[r] ? ~0u : 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t cm4 = (uint32_t)__builtin_amdgcn_sbfe((int)cand8[r], 8 * j + 7, 1);  // all ones for a candidate
+          const uint32_t cm4 = (uint32_t)__builtin_amdgcn_sbfe((int)cand8[r], 8 * j + CBIT, 1);  // all ones for a candidate
           if (INV) {
-            cor = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cor, 0xAE);    // cor | (~ncode & do)
+            // (the OR of the codes is kept on the planes: cor3 below -- one operation per row instead of one per pixel)
             op[j] = __builtin_amdgcn_bitop3_b32(code[r][j], dom, cm4, 0x5D);  // cand ? (~ncode & do) : all ones
           } else {
             cor |= code[r][j] & dom;
@@ -598,6 +608,15 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   HT_STAMP(5);   // code stores issued
   }  // tiles of this workgroup
   HT_STAMP_FLUSH();
+  if (INV) {
+    // bits 24 .. 30 from the last plane's bytes (only the n3 bits m3 selects are code bits); every lower bit the forest
+    // has: tests 0 .. 7 -> bits 0 .. 7, test 8 -> bit 0, tests 9 .. 24 -> bits 8 .. 23
+    uint32_t t = cor3 & m3;
+    t |= t >> 16;
+    t |= t >> 8;
+    const int lowbits = T <= 8 ? T : (T - 1 < 24 ? T - 1 : 24);
+    cor = ((t & 0x7Fu) << 24) | ((1u << lowbits) - 1u);
+  }
   if (!DENSE) {
     for (int o = 32; o > 0; o >>= 1) {
       cnt += __shfl_xor(cnt, o);
