@@ -505,12 +505,15 @@ def main():
         dom_us = 1e3 * dom_ms / max(dom_n, 1)
         achieved = alg.get(dom_slot, 0.0) / (dom_us * 1e-6) / 1e9 if dom_ms > 0 else 0.0
         # counters of the same workload from the committed rocprofv3 --pmc passes (never measured here)
-        prof = None
+        prof, valu_prof = None, None
         ppath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(ppath):
             try:
                 with open(ppath) as fh:
-                    prof = json.load(fh).get("%s@%dx%dx%d" % (dom_slot, W, H, B))
+                    tj = json.load(fh)
+                prof = tj.get("%s@%dx%dx%d" % (dom_slot, W, H, B))
+                # (the kernels are bound by vector-instruction issue, not by HBM: the committed PMC passes say how busy the VALUs were)
+                valu_prof = {k.split("@")[1]: v for k, v in tj.items() if k.startswith("valu_issue@") and k.endswith("@%dx%dx%d" % (W, H, B))} or None
             except Exception:
                 prof = None
         # SURVEY.md 8d's whole-pipeline figure: A = 10*W*H + 48*N + 12*M bytes per pair of a sort-based
@@ -526,6 +529,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "traffic_from_profiles": prof,
+            "valu_issue_from_profiles": valu_prof,
             "alg_bytes_per_launch": alg.get(dom_slot),
             "avg_launch_us": round(dom_us, 2),
             "launches_timed": dom_n,

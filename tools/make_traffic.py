@@ -37,6 +37,15 @@ def main():
             base = k.replace("gpc::", "").split("<")[0]
             base = alias.get(base, base)
             traffic["%s@%dx%dx%d" % (base, W, H, B)] = int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+    # how busy the vector ALUs were: SQ_ACTIVE_INST_VALU counts quad-cycles (one 4-clock issue slot per vector instruction),
+    # GRBM_GUI_ACTIVE the launch's clocks summed over the 8 XCDs; 256 CUs x 4 SIMDs
+    for k, d in summ.items():
+        if d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE"):
+            base = alias.get(k.replace("gpc::", "").split("<")[0], k.replace("gpc::", "").split("<")[0])
+            slots = d["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
+            traffic["valu_issue@%s@%dx%dx%d" % (base, W, H, B)] = {
+                "vector_instructions": int(d.get("SQ_INSTS_VALU", 0)), "valu_quad_cycles": int(d["SQ_ACTIVE_INST_VALU"]),
+                "quad_cycle_slots": int(slots), "frac": round(d["SQ_ACTIVE_INST_VALU"] / slots, 4)}
     json.dump(traffic, open(tpath, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
