@@ -100,6 +100,48 @@ def test_random_configuration(ctx, fused_ctx, oracle, forest_paths, seed):
             for q in (0, 2):
                 assert np.array_equal(o[q, :n, 0], got["x"]) and np.array_equal(o[q, :n, 1], got["y"])
                 assert np.array_equal(o[q, :n, 2].view(np.float32), got["d"])
+        # the reference's three calls through the two-step forms the C++ API uses: preprocess x2 (the images stay on the
+        # device), rectifiedMatch from the arrays as delivered (resident) or from copies of them (upload path), and the
+        # whole region as one call (matchPair's form)
+        gs = g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1)
+        pl, pr = ctx.preprocess_resident(L, thr), ctx.preprocess_resident(R, thr)
+        pre = oracle.preprocess_naive if naive else oracle.preprocess
+        for got_p, want_p in zip(pl + pr, pre(L, thr) + pre(R, thr)):
+            assert np.array_equal(got_p, want_p), (W, H, naive, thr)
+        h0 = ctx.resident_hits()
+        if seed % 4 == 1:
+            pl, pr = tuple(a.copy() for a in pl), tuple(a.copy() for a in pr)
+        s3, n3, st3, _ = ctx.match_async("rectified", pl, pr, gs)
+        assert ctx.resident_hits() == h0 + (0 if seed % 4 == 1 else 1)
+        assert st3 == 0 and n3 == n and np.array_equal(s3, got), (W, H, forest, epipolar, hashtable, naive, thr)
+        s4, n4, st4, nc4 = ctx.match_async("pair", L, R, gs, cap=(max(n // 2, 1) if seed % 5 == 2 else None))
+        assert n4 == n and nc4 == (nl, nr) and np.array_equal(s4, got[:len(s4)]) and len(s4) == (min(n, max(n // 2, 1)) if seed % 5 == 2 else n)
+        if epipolar and not hashtable and seed % 2 == 0:   # two lanes: the pair and its mirror in flight together, twice
+            import torch
+            dev = torch.device("cuda", 0)
+            fused_ctx.set_arithmetic(naive)
+            fused_ctx.load_forest(forest_paths[forest], W, H)
+            fused_ctx.set_pipeline(2)
+            try:
+                w2, l2, r2 = oracle.match_pair(R, L, f, sparsematch_settings(thr, disp_high, vtol, True, False, naive))
+                dA, dB = torch.from_numpy(np.stack([L])).to(dev), torch.from_numpy(np.stack([R])).to(dev)
+                capd = max(n, len(w2), 1) + W
+                outs = [torch.zeros((1, capd, 3), dtype=torch.int32, device=dev) for _ in range(4)]
+                cnts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(4)]
+                torch.cuda.synchronize(dev)
+                for k in range(4):
+                    a, b = (dA, dB) if k % 2 == 0 else (dB, dA)
+                    fused_ctx.match_batch_device(a.data_ptr(), b.data_ptr(), W, H, 1, gs, outs[k].data_ptr(), capd, cnts[k].data_ptr(), 0)
+                fused_ctx.synchronize()
+                for k in range(4):
+                    ref = got if k % 2 == 0 else w2.astype(got.dtype)
+                    o = outs[k].cpu().numpy()[0]
+                    assert int(cnts[k].item()) == len(ref)
+                    assert np.array_equal(o[:len(ref), 0], ref["x"]) and np.array_equal(o[:len(ref), 1], ref["y"])
+                    assert np.array_equal(o[:len(ref), 2].view(np.float32), ref["d"])
+            finally:
+                fused_ctx.set_pipeline(1)
+                fused_ctx.set_arithmetic(False)
         if seed % 3 == 0:  # the batch entry point on the same shape: pair 1 swaps the images
             out, counts, nc, st = ctx.match_batch(np.stack([L, R]), np.stack([R, L]),
                                                   g.Settings(thr, disp_high, vtol, epipolar, hashtable, 1), max(n, 1) * 2 + W * H)
