@@ -193,42 +193,6 @@ class Forest {
     return result;
   }
 
-  // What the reference's caller does next -- preprocessImage x2, rectifiedMatch / matchPair on images of this size --
-  // done once here on a synthetic image and thrown away: context, code objects, workspaces and page-locked staging
-  // (gpc_hip_warmup), and this thread's own staging and the allocator's state for result arrays of this size (the dry run
-  // below).  Says nothing and leaves no status when it cannot run (no device: the first real call reports that).
-  void warmUp(FilterMask& forestmask) {
-    detail::ContextHolder& h = detail::holder(true);
-    if (!h.ctx) return;
-    gpc_filter_mask key;
-    if (!toC(forestmask, key)) return;
-    if (h.have_warmed && memcmp(&h.warmed, &key, sizeof key) == 0) return;
-    if (gpc_hip_set_forest(h.ctx, &key) != GPC_OK) return;
-    h.uploaded = key;
-    h.have = true;
-    if (gpc_hip_warmup(h.ctx, forestmask.width, forestmask.height, nullptr) != GPC_OK) return;
-    ndb::Buffer<uint8_t> img(forestmask.height, forestmask.width);
-    for (int y = 0; y < img.rows(); ++y)
-      for (int x = 0; x < img.cols(); ++x) {
-        uint32_t v = ((uint32_t)(x >> 2) * 73856093u) ^ ((uint32_t)(y >> 2) * 19349663u);
-        v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13;
-        img(y, x) = (uint8_t)(v >> 9);
-      }
-    const int st0 = detail::last_status();
-    const std::string err0 = detail::last_error();
-    InferenceSettings sparse(5, 128, 0, true, false, 1);
-    for (int it = 0; it < 2; ++it) {
-      PreprocessedImage a = preprocessImage(img, sparse), b = preprocessImage(img, sparse);
-      std::vector<ndb::Support> r = rectifiedMatch(a, b, forestmask, sparse);
-      std::vector<ndb::Support> f = matchPair(img, img, forestmask, sparse);
-      h.support_hint = 0;  // (a pair matched against itself says nothing about the caller's)
-    }
-    detail::last_status() = st0;
-    detail::last_error() = err0;
-    h.warmed = key;
-    h.have_warmed = true;
-  }
-
   // inference.hpp:302-333
   PreprocessedImage preprocessImage(ndb::Buffer<uint8_t>& img, InferenceSettings settings) {
     assert((settings.gradientThreshold_ >= 0 && settings.gradientThreshold_ <= 255) &&
@@ -352,6 +316,42 @@ class Forest {
   }
 
  private:
+  // What the reference's caller does next -- preprocessImage x2, rectifiedMatch / matchPair on images of this size --
+  // done once here on a synthetic image and thrown away: context, code objects, workspaces and page-locked staging
+  // (gpc_hip_warmup), and this thread's own staging and the allocator's state for result arrays of this size (the dry run
+  // below).  Says nothing and leaves no status when it cannot run (no device: the first real call reports that).
+  void warmUp(FilterMask& forestmask) {
+    detail::ContextHolder& h = detail::holder(true);
+    if (!h.ctx) return;
+    gpc_filter_mask key;
+    if (!toC(forestmask, key)) return;
+    if (h.have_warmed && memcmp(&h.warmed, &key, sizeof key) == 0) return;
+    if (gpc_hip_set_forest(h.ctx, &key) != GPC_OK) return;
+    h.uploaded = key;
+    h.have = true;
+    if (gpc_hip_warmup(h.ctx, forestmask.width, forestmask.height, nullptr) != GPC_OK) return;
+    ndb::Buffer<uint8_t> img(forestmask.height, forestmask.width);
+    for (int y = 0; y < img.rows(); ++y)
+      for (int x = 0; x < img.cols(); ++x) {
+        uint32_t v = ((uint32_t)(x >> 2) * 73856093u) ^ ((uint32_t)(y >> 2) * 19349663u);
+        v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13;
+        img(y, x) = (uint8_t)(v >> 9);
+      }
+    const int st0 = detail::last_status();
+    const std::string err0 = detail::last_error();
+    InferenceSettings sparse(5, 128, 0, true, false, 1);
+    for (int it = 0; it < 2; ++it) {
+      PreprocessedImage a = preprocessImage(img, sparse), b = preprocessImage(img, sparse);
+      std::vector<ndb::Support> r = rectifiedMatch(a, b, forestmask, sparse);
+      std::vector<ndb::Support> f = matchPair(img, img, forestmask, sparse);
+      h.support_hint = 0;  // (a pair matched against itself says nothing about the caller's)
+    }
+    detail::last_status() = st0;
+    detail::last_error() = err0;
+    h.warmed = key;
+    h.have_warmed = true;
+  }
+
   static int countFerns(const std::string& path) {
     FILE* fp = fopen(path.c_str(), "rb");
     int n = 0;

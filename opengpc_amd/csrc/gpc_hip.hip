@@ -91,16 +91,23 @@ class ExpandPool {
   ~ExpandPool() { stop(); }
   // bind: CPUs the workers may run on (the NUMA node of the GPU: the page-locked buffers they read and write live there,
   // and workers that land on the other socket made the same call take 7.3 instead of 5.4 ms); null = wherever
-  void start(int nthreads, const cpu_set_t* bind) {
+  // bind: the CPUs of the GPU's NUMA node.  groups: the same CPUs by last-level cache (one set per CCD): worker i is held on
+  // group i mod n.  Left to the scheduler, workers woken by one thread are placed on idle CPUs of the WAKER's cache domain --
+  // all eight on one CCD, whose link to the memory controllers then carries every record they write: the same 256-pair call
+  // took 8.5 ms instead of 5.3 (profiles/r05_g_bench.json against r05_e: worker CPUs 64-71 + their SMT siblings).
+  void start(int nthreads, const cpu_set_t* bind, const std::vector<cpu_set_t>* groups = nullptr) {
     if ((int)threads_.size() == nthreads) return;
     stop();
     quit_ = false;
     have_bind_ = bind != nullptr;
     if (bind) bind_ = *bind;
+    groups_.clear();
+    if (bind && groups) groups_ = *groups;
     cpus_.assign((size_t)nthreads, -1);
     for (int i = 0; i < nthreads; ++i)
       threads_.emplace_back([this, i] {
-        if (have_bind_) (void)sched_setaffinity(0, sizeof bind_, &bind_);
+        if (!groups_.empty()) (void)sched_setaffinity(0, sizeof(cpu_set_t), &groups_[(size_t)i % groups_.size()]);
+        else if (have_bind_) (void)sched_setaffinity(0, sizeof bind_, &bind_);
         run(i);
       });
   }
@@ -148,6 +155,7 @@ class ExpandPool {
   bool quit_ = false;
   bool have_bind_ = false;
   cpu_set_t bind_;
+  std::vector<cpu_set_t> groups_;
 };
 
 }  // namespace
@@ -181,6 +189,7 @@ struct gpc_hip_ctx {
                                   // kernels straight into the caller's array (no packed records, no host expansion); 0 = never
   bool have_node_cpus = false;    // CPUs of the NUMA node this GPU hangs off (from sysfs), within the process's affinity mask
   cpu_set_t node_cpus;
+  std::vector<cpu_set_t> node_l3;  // node_cpus by last-level cache (CCD): the expansion workers are dealt over these
   int numa_node = -1;
   // Two lanes (gpc_hip_set_pipeline): consecutive device-resident batch calls alternate between two sets of workspaces on
   // two streams of the context's own, wired with events so that batch k+1's k_preprocess and k_hash run beside batch k's
@@ -474,6 +483,37 @@ void find_gpu_node_cpus(gpc_hip_ctx* c) {
   if (CPU_COUNT(&c->node_cpus) < 2) return;  // nothing sensible to bind to
   c->numa_node = node;
   c->have_node_cpus = true;
+  // the node's CPUs by last-level cache: /sys/devices/system/cpu/cpuN/cache/index3/shared_cpu_list ("64-71,192-199")
+  c->node_l3.clear();
+  if (getenv("GPC_HIP_NO_CCD_SPREAD")) return;
+  cpu_set_t seen;
+  CPU_ZERO(&seen);
+  for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+    if (!CPU_ISSET(cpu, &c->node_cpus) || CPU_ISSET(cpu, &seen)) continue;
+    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE* f3 = fopen(path, "r");
+    if (!f3) { c->node_l3.clear(); return; }
+    char l3[1024] = {0};
+    const size_t g3 = fread(l3, 1, sizeof l3 - 1, f3);
+    fclose(f3);
+    l3[g3] = 0;
+    cpu_set_t grp;
+    CPU_ZERO(&grp);
+    for (const char* p = l3; *p;) {
+      while (*p && !isdigit((unsigned char)*p)) ++p;
+      if (!*p) break;
+      char* e = nullptr;
+      long a = strtol(p, &e, 10), b = a;
+      p = e;
+      if (*p == '-') b = strtol(p + 1, &e, 10), p = e;
+      for (long k = a; k <= b && k < CPU_SETSIZE; ++k)
+        if (CPU_ISSET((int)k, &c->node_cpus)) CPU_SET((int)k, &grp);
+    }
+    if (CPU_COUNT(&grp) == 0) CPU_SET(cpu, &grp);
+    CPU_OR(&seen, &seen, &grp);
+    c->node_l3.push_back(grp);
+  }
+  if (c->node_l3.size() < 2) c->node_l3.clear();  // one cache domain: nothing to spread over
 }
 
 // Worker threads gpc_hip_match_batch may start for the host expansion when nobody said how many: the process's CPUs
@@ -621,15 +661,23 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
   CHK(ensure(c, c->stats, sizeof(int32_t) * GPC_STAT_STRIDE * nimg));
   // threshold^2 passes through _mm_set1_epi16 in the SSE build (filter.hpp:418); sobelNaive keeps the int (:159)
   const int thr_sq = c->naive ? (thr & 0xFF) * (thr & 0xFF) : (int)(int16_t)(uint16_t)((thr & 0xFF) * (thr & 0xFF));
-  // 14 rows per thread read every raw row 1.14 times; launches that would not fill the device with such strips
-  // (fewer than 1024 workgroups: 4 per CU) use 6 rows per thread, and those that still would not (a single pair) 2 --
-  // more workgroups, shorter chains
+  // Rows per thread (the strip a thread marches down): 14 read every raw row 1.14 times and are what a launch that fills the
+  // device many times over wants; a smaller launch is a matter of ROUNDS -- the device holds 8 workgroups per CU, and a launch
+  // of 1.2 rounds takes two -- so the strip height is the one whose rounds x (rows + 2 read + ~2 of set-up) comes out lowest:
+  // 64 images of 1024x436 are 1024 workgroups of 14-row strips (half a round of long chains: 23 us), 2432 of 6-row ones
+  // (1.2 rounds: 21 us) and exactly 2048 of 7-row ones (one round).
   const int gx = (W / PP_PX + PP_TX - 1) / PP_TX;
   auto blocks_with = [&](int r) { return (long)gx * ((H + PP_TY * r - 1) / (PP_TY * r)) * nimg; };
-  // (measured per launch, 1024x436: 32 pairs -- 1024 workgroups of 14-row strips, 2432 of 6-row ones -- 23.2 / 21.0 us;
-  //  64 pairs 35.2 / 35.0; 16 pairs take the 6-row strips either way, 2-row ones are slower from 16 pairs on)
-  const int rows = c->pre_rows ? c->pre_rows
-                               : (blocks_with(PP_ROWS) >= 2048 ? PP_ROWS : (blocks_with(PP_ROWS_MID) >= 1024 ? PP_ROWS_MID : PP_ROWS_SMALL));
+  int rows = c->pre_rows;
+  if (!rows) {
+    static const int heights[] = {PP_ROWS, 10, 7, PP_ROWS_MID, 4, PP_ROWS_SMALL};
+    const long places = 8l * (c->num_cus > 0 ? c->num_cus : 256);
+    long best = -1;
+    for (int r : heights) {
+      const long cost = (blocks_with(r) + places - 1) / places * (r + 4);
+      if (best < 0 || cost < best) { best = cost; rows = r; }   // (ties go to the taller strip: fewer re-read rows)
+    }
+  }
   dim3 grid(gx, (H + PP_TY * rows - 1) / (PP_TY * rows), nimg);
   Timed t(c, KID_PREPROCESS);
   // (the SSE=OFF arithmetic keeps the byte image: its 32-test codes need the candidate BYTES in the matchers, wide_codes())
@@ -642,7 +690,10 @@ int run_preprocess(gpc_hip_ctx* c, const uint8_t* d_raw0, const uint8_t* d_raw1,
 #define LAUNCH_PRE_ROWS(NAIVE, BITS)                                  \
   do {                                                                \
     if (rows == PP_ROWS) LAUNCH_PRE(NAIVE, PP_ROWS, BITS);            \
+    else if (rows == 10) LAUNCH_PRE(NAIVE, 10, BITS);                 \
+    else if (rows == 7) LAUNCH_PRE(NAIVE, 7, BITS);                   \
     else if (rows == PP_ROWS_MID) LAUNCH_PRE(NAIVE, PP_ROWS_MID, BITS); \
+    else if (rows == 4) LAUNCH_PRE(NAIVE, 4, BITS);                   \
     else LAUNCH_PRE(NAIVE, PP_ROWS_SMALL, BITS);                      \
   } while (0)
   if (c->naive) LAUNCH_PRE_ROWS(true, false);
@@ -1739,7 +1790,7 @@ int ensure_pool(gpc_hip_ctx* c) {
   if (c->pool.size() == 0) {
     int nt = c->expand_threads > 0 ? c->expand_threads : default_expand_threads();
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
-    c->pool.start(nt, c->have_node_cpus ? &c->node_cpus : nullptr);
+    c->pool.start(nt, c->have_node_cpus ? &c->node_cpus : nullptr, &c->node_l3);
   }
   return GPC_OK;
 }
@@ -1851,7 +1902,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (const char* e = getenv("GPC_HIP_HASH_TALL")) c->hash_tall = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GPC_HIP_PRE_ROWS")) {
     const int v = atoi(e);
-    if (v == PP_ROWS || v == PP_ROWS_MID || v == PP_ROWS_SMALL) c->pre_rows = v;
+    if (v == PP_ROWS || v == 10 || v == 7 || v == PP_ROWS_MID || v == 4 || v == PP_ROWS_SMALL) c->pre_rows = v;
   }
   c->fuse_always = getenv("GPC_HIP_FUSE_ALWAYS") != nullptr;
   if (const char* e = getenv("GPC_HIP_FUSE_WGS")) {
@@ -2918,7 +2969,7 @@ static int match_batch_packed(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t
     // shared by both directions being the limit; 14 workers on a 16-CPU share: 10.9 ms)
     int nt = c->expand_threads > 0 ? c->expand_threads : (s->num_threads > 1 ? s->num_threads : default_expand_threads());
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
-    c->pool.start(nt, c->have_node_cpus ? &c->node_cpus : nullptr);
+    c->pool.start(nt, c->have_node_cpus ? &c->node_cpus : nullptr, &c->node_l3);
   }
   uint8_t* d_pk = (uint8_t*)c->packed.p;
   uint8_t* h_pk = (uint8_t*)c->h_stage;

@@ -57,9 +57,9 @@ def test_preprocess(ctx, oracle, W, H, thr):
         assert np.array_equal(m, mo)
 
 
-@pytest.mark.parametrize("rows", [14, 6, 2])
+@pytest.mark.parametrize("rows", [14, 10, 7, 6, 4, 2])
 def test_preprocess_every_strip_height_on_ragged_images(oracle, forest_paths, rows):
-    """k_preprocess has three instantiations (14 / 6 / 2 rows per thread) picked by the launch's size: each forced
+    """k_preprocess has six strip heights (14 / 10 / 7 / 6 / 4 / 2 rows per thread) picked by the launch's size: each forced
     (GPC_HIP_PRE_ROWS) on heights that leave the last strip -- and the last block of four strips -- partly or wholly empty,
     in both arithmetics, and through a whole match_pair."""
     import opengpc_amd as g

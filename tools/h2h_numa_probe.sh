@@ -31,10 +31,14 @@ for _ in range(11):
     t0 = time.perf_counter(); ctx.match_batch(Lp, Rp, s, cap, out=out); tt.append(time.perf_counter() - t0); st.append(ctx.batch_stages())
 tt.sort()
 print(json.dumps({"tag": sys.argv[1], "ms": round(tt[5] * 1e3, 3), "stages": stage_summary(st), "cpu": current_cpu(), "node": cpu_nodes().get(current_cpu()),
-                  "pages": {"out": pages_nodes(out), "images": pages_nodes(Lp)}, "workers": sorted(set(cpu_nodes().get(c) for c in ctx.worker_cpus())),
+                  "pages": {"out": pages_nodes(out), "images": pages_nodes(Lp)}, "workers": sorted(set(cpu_nodes().get(c) for c in ctx.worker_cpus())), "worker_cpus": sorted(ctx.worker_cpus()),
                   "gpu_node": ctx.L.gpc_hip_host_numa_node(ctx.h), "fed_calls": ctx.L.gpc_hip_fed_calls(ctx.h)}))
 ctx.close()
 PY
+python /tmp/h2h.py unpinned_workers_one_per_ccd | tee -a gpurun_out/r05d/h2h_numa.txt
+GPC_HIP_NO_CCD_SPREAD=1 python /tmp/h2h.py unpinned_workers_where_the_scheduler_puts_them | tee -a gpurun_out/r05d/h2h_numa.txt
+python /tmp/h2h.py unpinned_workers_one_per_ccd | tee -a gpurun_out/r05d/h2h_numa.txt
+GPC_HIP_NO_CCD_SPREAD=1 python /tmp/h2h.py unpinned_workers_where_the_scheduler_puts_them | tee -a gpurun_out/r05d/h2h_numa.txt
 taskset -c $N0 python /tmp/h2h.py process_confined_to_node0 | tee -a gpurun_out/r05d/h2h_numa.txt
 GPC_PIN_CALLER=$(( $(echo $N0 | cut -d, -f1 | cut -d- -f1) + 9 )) python /tmp/h2h.py caller_thread_on_node0_feeder | tee -a gpurun_out/r05d/h2h_numa.txt
 GPC_HIP_NO_FEEDER=1 GPC_PIN_CALLER=$(( $(echo $N0 | cut -d, -f1 | cut -d- -f1) + 9 )) python /tmp/h2h.py caller_thread_on_node0_no_feeder | tee -a gpurun_out/r05d/h2h_numa.txt
