@@ -209,6 +209,7 @@ struct gpc_hip_ctx {
   // device-resident batch call waits for before k_preprocess / between k_preprocess and k_hash, and records after k_hash /
   // after the join -- enough to let one batch's k_preprocess run beside the previous batch's join and nothing else
   hipEvent_t dbg_wait_pre = nullptr, dbg_wait_hash = nullptr, dbg_rec_hash = nullptr, dbg_rec_join = nullptr;
+  bool no_pair_packed = false;    // GPC_HIP_NO_PAIR_PACKED: the two-step forms deliver 12-byte records over the link (A/B checks)
   bool no_feeder = false;         // GPC_HIP_NO_FEEDER: the chunk pipeline always runs on the calling thread (A/B checks)
   int fed_calls = 0;              // batch calls that ran on a feeder thread (gpc_hip_fed_calls)
   int chunk_pairs = 0;            // GPC_HIP_CHUNK: pairs per chunk of gpc_hip_match_batch (tuning)
@@ -306,8 +307,10 @@ struct gpc_hip_ctx {
   // caller's page-locked array), the count and the candidate counts in h_cnt[0 .. 2]
   struct PendingMatch {
     bool active = false, direct = false, have_ncand = false;
+    bool packed = false;   // the arena holds [H row counts | cap_dev words xL | xR << 16] (epipolar sort-matcher): 4 bytes
+                           // per support over the link instead of 12, expanded into the caller's array by the workers
     size_t esz = 0;
-    int cap_dev = 0;
+    int cap_dev = 0, H = 0;
   } pend;
   bool debug = false;           // GPC_HIP_DEBUG: launch geometry on stderr
   bool debug_plan = false;      // GPC_HIP_DEBUG_PLAN: the hash-table planner's choice on stderr
@@ -1898,6 +1901,7 @@ int gpc_hip_create(int device, gpc_hip_ctx** out) {
   if (const char* e = getenv("GPC_HIP_UPLOAD")) c->upload_mode = atoi(e);
   c->no_grad_bits = getenv("GPC_HIP_NO_GRAD_BITS") != nullptr;
   c->no_feeder = getenv("GPC_HIP_NO_FEEDER") != nullptr;
+  c->no_pair_packed = getenv("GPC_HIP_NO_PAIR_PACKED") != nullptr;
   c->no_fuse = getenv("GPC_HIP_NO_FUSE") != nullptr;
   if (const char* e = getenv("GPC_HIP_HASH_TALL")) c->hash_tall = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GPC_HIP_PRE_ROWS")) {
@@ -2368,7 +2372,13 @@ static int match_preprocessed_begin(gpc_hip_ctx* c, const uint8_t* smoothL, cons
   CHK(pinned_counts(c, 1));
   int32_t* d_cnt = nullptr;
   HIPCHK(c, hipHostGetDevicePointer((void**)&d_cnt, c->h_cnt, 0));
-  const size_t out_bytes = pad16(esz * (size_t)(cap_dev > 0 ? cap_dev : 1));
+  // Supports of the epipolar sort-matcher cross the link PACKED (x | xR << 16 + the row counts: 4 bytes instead of 12 -- a
+  // 1024x436 pair's 3.2 MB of records were 60 us of the link, a third of the call) and are expanded into the caller's
+  // array by the worker threads, who read 1.1 MB where they copied 3.2
+  const bool packed = mode == 0 && !direct_out && s->epipolar_mode && !s->use_hashtable && !c->no_pair_packed;
+  const size_t rows_bytes = pad16(sizeof(int32_t) * (size_t)H);
+  const size_t out_bytes = packed ? rows_bytes + pad16(sizeof(uint32_t) * (size_t)(cap_dev > 0 ? cap_dev : 1))
+                                  : pad16(esz * (size_t)(cap_dev > 0 ? cap_dev : 1));
   const int sl = resident_slot(c, smoothL, gradL, maskL, nL, W, H);
   const int sr = sl >= 0 ? resident_slot(c, smoothR, gradR, maskR, nR, W, H) : -1;
   const bool resident = sl >= 0 && sr >= 0;
@@ -2435,12 +2445,19 @@ static int match_preprocessed_begin(gpc_hip_ctx* c, const uint8_t* smoothL, cons
   c->grad_is_bits = false;  // byte images
   hipLaunchKernelGGL(gpc::k_stats_init, dim3(1), dim3(64), 0, c->stream, (int32_t*)c->stats.p, 2);
   CHK(run_hash(c, d_sm, d_gr, resident ? nullptr : d_cand, W, H, 2, false, (uint32_t*)c->codes.p));
-  CHK(run_match(c, W, H, 1, s, mode, d_cand, d_out, cap_dev, d_cnt, nullptr));
+  if (packed) {
+    const PackedOut po = {reinterpret_cast<int32_t*>(d_arena), (long)cap_dev, (long)H};
+    CHK(run_match(c, W, H, 1, s, 2, d_cand, d_arena + rows_bytes, cap_dev, d_cnt, nullptr, &po));
+  } else {
+    CHK(run_match(c, W, H, 1, s, mode, d_cand, d_out, cap_dev, d_cnt, nullptr));
+  }
   c->pend.active = true;
   c->pend.direct = direct_out != nullptr;
   c->pend.have_ncand = false;
+  c->pend.packed = packed;
   c->pend.esz = esz;
   c->pend.cap_dev = cap_dev;
+  c->pend.H = H;
   return GPC_OK;
 }
 
@@ -2458,7 +2475,24 @@ static int match_fetch(gpc_hip_ctx* c, void* out, int cap, int* n_out, int* ncl,
   }
   int ncopy = cnt < cap ? cnt : cap;
   if (ncopy > c->pend.cap_dev) ncopy = c->pend.cap_dev;
-  if (!c->pend.direct && ncopy > 0) {
+  if (c->pend.packed && ncopy > 0) {
+    const int H = c->pend.H;
+    const int32_t* rows = reinterpret_cast<const int32_t*>(c->h_xfer);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(c->h_xfer + pad16(sizeof(int32_t) * (size_t)H));
+    const bool par = ncopy >= 32 * 1024;
+    if (par) CHK(ensure_pool(c));
+    const int parts = par ? (c->pool.size() > 1 ? c->pool.size() : 1) : 1;
+    long first = 0;
+    for (int q = 0; q < parts; ++q) {
+      const int y0 = GPC_R + (int)((long)(H - 2 * GPC_R) * q / parts), y1 = GPC_R + (int)((long)(H - 2 * GPC_R) * (q + 1) / parts);
+      if (first < ncopy && y1 > y0) {
+        if (par) c->pool.push(ExpandJob{words, rows, H, y0, y1, (int)first, ncopy, static_cast<gpc_support*>(out), 6});
+        else expand_rows(words, rows, y0, y1, first, ncopy, static_cast<gpc_support*>(out));
+      }
+      for (int y = y0; y < y1; ++y) first += rows[y];
+    }
+    if (par) host_copy_wait(c);
+  } else if (!c->pend.direct && ncopy > 0) {
     const size_t bytes = c->pend.esz * (size_t)ncopy;
     const bool par = bytes >= 256 * 1024;
     if (par) CHK(ensure_pool(c));
@@ -3136,7 +3170,9 @@ int gpc_hip_match_pair_begin(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t*
   c->pre_slot = -1;
   const size_t n = (size_t)W * H;
   const int cap_dev = (W - 2 * GPC_R) * (H - 2 * GPC_R) + 1;  // no pair has more supports than an image has candidates
-  const size_t out_bytes = pad16(sizeof(gpc_support) * (size_t)cap_dev);
+  const bool packed = s->epipolar_mode && !s->use_hashtable && !c->no_pair_packed;  // (as in match_preprocessed_begin)
+  const size_t rows_bytes = pad16(sizeof(int32_t) * (size_t)H);
+  const size_t out_bytes = packed ? rows_bytes + pad16(sizeof(uint32_t) * (size_t)cap_dev) : pad16(sizeof(gpc_support) * (size_t)cap_dev);
   CHK(ensure(c, c->raw, 2 * n));
   CHK(ensure(c, c->codes, sizeof(uint32_t) * n * 2));
   CHK(pinned_counts(c, 1));
@@ -3160,12 +3196,19 @@ int gpc_hip_match_pair_begin(gpc_hip_ctx* c, const uint8_t* rawL, const uint8_t*
   HIPCHK(c, hipGetLastError());
   CHK(run_preprocess(c, d_l, d_r, W, H, 1, 2, s->gradient_threshold, true));
   CHK(run_hash(c, (const uint8_t*)c->smooth.p, (const uint8_t*)c->grad.p, nullptr, W, H, 2, false, (uint32_t*)c->codes.p));
-  CHK(run_match(c, W, H, 1, s, 0, (const uint8_t*)c->grad.p, d_arena, cap_dev, d_cnt, d_cnt + 1));
+  if (packed) {
+    const PackedOut po = {reinterpret_cast<int32_t*>(d_arena), (long)cap_dev, (long)H};
+    CHK(run_match(c, W, H, 1, s, 2, (const uint8_t*)c->grad.p, d_arena + rows_bytes, cap_dev, d_cnt, d_cnt + 1, &po));
+  } else {
+    CHK(run_match(c, W, H, 1, s, 0, (const uint8_t*)c->grad.p, d_arena, cap_dev, d_cnt, d_cnt + 1));
+  }
   c->pend.active = true;
   c->pend.direct = false;
   c->pend.have_ncand = true;
+  c->pend.packed = packed;
   c->pend.esz = sizeof(gpc_support);
   c->pend.cap_dev = cap_dev;
+  c->pend.H = H;
   return GPC_OK;
 }
 

@@ -237,3 +237,38 @@ def test_two_step_forms(ctx, oracle, forest_paths, epipolar, hashtable):
     k = C.c_int()
     ctx.match_pair(L, R, gs)
     assert ctx.L.gpc_hip_preprocess_fetch(ctx.h, None, None, None, 0, C.byref(k)) == g.capi.E_INVALID
+
+
+def test_pair_results_packed_over_the_link_equal_the_12_byte_form(oracle, forest_paths, monkeypatch):
+    """The two-step forms bring an epipolar pair's supports over the link packed (4 bytes each + row counts) and expand them
+    into the caller's array on the library's threads; GPC_HIP_NO_PAIR_PACKED=1 keeps the 12-byte records.  Same results, also
+    with a capacity that cuts a row in two and with a fetch repeated after GPC_E_CAPACITY."""
+    import opengpc_amd as g
+    W, H = 1024, 436
+    L, R = oracle.synth_pair(W, H, 0, 24)
+    rc, f = oracle.read_forest(forest_paths["zero"], W, H)
+    want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings())
+    gs = g.Settings.sparsematch()
+    res = {}
+    for packed in (True, False):
+        if packed:
+            monkeypatch.delenv("GPC_HIP_NO_PAIR_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("GPC_HIP_NO_PAIR_PACKED", "1")
+        c = g.Context(0)
+        try:
+            c.load_forest(forest_paths["zero"], W, H)
+            supp, n, st, nc = c.match_async("pair", L, R, gs)
+            assert st == 0 and nc == (nl, nr) and np.array_equal(supp, want)
+            cut = len(want) // 2 + 7            # ends inside a row
+            supp, n, st, nc = c.match_async("pair", L, R, gs, cap=cut)      # (match_async fetches again after E_CAPACITY and compares)
+            assert st == g.capi.E_CAPACITY and n == len(want) and np.array_equal(supp, want[:cut])
+            pl, pr = c.preprocess_resident(L, 5), c.preprocess_resident(R, 5)
+            supp, n, st, _ = c.match_async("rectified", pl, pr, gs)
+            assert st == 0 and np.array_equal(supp, want)
+            supp, n, st = c.rectified_match(pl, pr, gs)                     # the synchronous form, pageable `out`
+            assert st == 0 and np.array_equal(supp, want)
+            res[packed] = supp
+        finally:
+            c.close()
+    assert np.array_equal(res[True], res[False])
