@@ -1687,7 +1687,7 @@ void host_copy(gpc_hip_ctx* c, void* dst, const void* src, size_t bytes, bool pa
   }
 }
 void host_copy_wait(gpc_hip_ctx* c) {
-  if (c->pool.size() >= 2) c->pool.wait_slot(6);
+  if (c->pool.size() >= 1) c->pool.wait_slot(6);  // (whoever pushed: returns at once when nothing is pending)
 }
 
 // at least `bytes` of transfer arena; *dev receives the device's view of it

@@ -250,11 +250,15 @@ def test_pair_results_packed_over_the_link_equal_the_12_byte_form(oracle, forest
     want, nl, nr = oracle.match_pair(L, R, f, sparsematch_settings())
     gs = g.Settings.sparsematch()
     res = {}
-    for packed in (True, False):
+    for packed, workers in ((True, None), (False, None), (True, "1"), (False, "1"), (True, "3")):
         if packed:
             monkeypatch.delenv("GPC_HIP_NO_PAIR_PACKED", raising=False)
         else:
             monkeypatch.setenv("GPC_HIP_NO_PAIR_PACKED", "1")
+        if workers:      # one worker thread: the jobs are still waited for; three: row ranges that do not divide evenly
+            monkeypatch.setenv("GPC_HIP_EXPAND_THREADS", workers)
+        else:
+            monkeypatch.delenv("GPC_HIP_EXPAND_THREADS", raising=False)
         c = g.Context(0)
         try:
             c.load_forest(forest_paths["zero"], W, H)
@@ -268,7 +272,9 @@ def test_pair_results_packed_over_the_link_equal_the_12_byte_form(oracle, forest
             assert st == 0 and np.array_equal(supp, want)
             supp, n, st = c.rectified_match(pl, pr, gs)                     # the synchronous form, pageable `out`
             assert st == 0 and np.array_equal(supp, want)
-            res[packed] = supp
+            assert c.L.gpc_hip_host_threads(c.h) == (int(workers) if workers else c.L.gpc_hip_host_threads(c.h))
+            res[(packed, workers)] = supp
         finally:
             c.close()
-    assert np.array_equal(res[True], res[False])
+    for v in res.values():
+        assert np.array_equal(v, res[(True, None)])
