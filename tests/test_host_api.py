@@ -15,10 +15,10 @@ REF_SAMPLE = "/root/reference/samples/sparsematch.cpp"
 REF_ON_AMD = os.path.join(ROOT, "oracle", "_ref", "ref_sparsematch_on_amd_headers")
 
 
-def compile_cpp(src, out, sse=True):
+def compile_cpp(src, out, sse=True, opt="-O1"):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # -D_INTRINSICS_SSE is the reference's default build option (samples/CMakeLists.txt:13-17)
-    subprocess.check_call(["g++", "-std=c++17", "-O1"] + (["-D_INTRINSICS_SSE"] if sse else []) +
+    subprocess.check_call(["g++", "-std=c++17", opt] + (["-D_INTRINSICS_SSE"] if sse else []) +
                           ["-I" + os.path.join(ROOT, "include"), "-o", out, src,
                            "-L" + LIBDIR, "-lgpc_hip", "-lz", "-lpthread",
                            "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
@@ -174,7 +174,7 @@ def test_clear_boundary(check_bin, tmp_path, oracle):
 def test_reference_sample_compiles_unchanged_against_these_headers():
     """Drop-in at source level: the reference's samples/sparsematch.cpp, untouched, builds
     against include/gpc/*.hpp.  The binary goes to oracle/_ref (derived from reference source)."""
-    compile_cpp(REF_SAMPLE, REF_ON_AMD)
+    compile_cpp(REF_SAMPLE, REF_ON_AMD, opt="-O3")     # the reference's own optimisation level (samples/CMakeLists.txt:17)
     assert os.path.exists(REF_ON_AMD)
 
 

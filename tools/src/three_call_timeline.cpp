@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
   std::vector<gpc_support> supp;
   for (int it = 0; it < iters; ++it) {
     if (it == 5) { g_t.clear(); g_order.clear(); }
+    const bool show = it < 4 && getenv("TL_FIRST");   // the first calls of the process, stage by stage
     Pre p[2];
     Lap lap;
     double t_pre = 0;
@@ -102,6 +103,11 @@ int main(int argc, char** argv) {
     g_order.erase(std::unique(g_order.begin(), g_order.end()), g_order.end());
     g_t["tPreprocess"].push_back(t_pre);
     g_t["tPreprocess + tMatch"].push_back(t_all);
+    if (show) {
+      printf("call %d:", it + 1);
+      for (auto& k : g_order) printf("  %s %.0f", k.c_str(), g_t[k].back());
+      printf("\n");
+    }
   }
   printf("%dx%d, %zu supports, %d warm iterations%s; medians in us (per call; the preprocess stages are per image)\n", W, H, supp.size(),
          iters - 5, getenv("TL_MALLOPT") ? ", mallopt(no trim, no mmap)" : "");
