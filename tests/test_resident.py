@@ -278,3 +278,41 @@ def test_pair_results_packed_over_the_link_equal_the_12_byte_form(oracle, forest
             c.close()
     for v in res.values():
         assert np.array_equal(v, res[(True, None)])
+
+
+def test_two_host_threads_with_a_context_each(oracle, forest_paths):
+    """The reference's Forest is stateless and re-entrant; here every host thread has a context of its own.  Two threads run
+    the three-call sequence concurrently (ctypes releases the GIL: the library calls really overlap) on different pairs: the
+    records of resident images are per context, the table of them is shared and locked."""
+    import threading
+    import opengpc_amd as g
+    W, H = 304, 75
+    rc, f = oracle.read_forest(forest_paths["tau"], W, H)
+    gs, os_ = g.Settings.sparsematch(), sparsematch_settings()
+    pairs = [oracle.synth_pair(W, H, 11, 6), oracle.synth_pair(W, H, 12, 17)]
+    wants = [oracle.match_pair(L, R, f, os_)[0] for L, R in pairs]
+    errors = []
+
+    def work(k):
+        try:
+            c = g.Context(0)
+            try:
+                c.load_forest(forest_paths["tau"], W, H)
+                L, R = pairs[k]
+                for it in range(40):
+                    pl, pr = c.preprocess_resident(L, 5), c.preprocess_resident(R, 5)
+                    h0 = c.resident_hits()
+                    supp, n, st = c.rectified_match(pl, pr, gs)
+                    assert st == 0 and c.resident_hits() == h0 + 1 and np.array_equal(supp, wants[k]), (k, it)
+                    s2, n2, st2, nc = c.match_async("pair", L, R, gs)
+                    assert st2 == 0 and np.array_equal(s2, wants[k]), (k, it)
+            finally:
+                c.close()
+        except Exception as e:     # (an assertion in a thread must fail the test)
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
