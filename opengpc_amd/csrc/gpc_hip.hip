@@ -3599,6 +3599,16 @@ extern "C" int gpc_hip_debug_expand_pool(const uint32_t* packed, const int32_t* 
   return GPC_OK;
 }
 
+// Host-only test hook (tests/cpp/sanitize_host.cpp, sanitizer builds on the CPU; not part of the C ABI): the fingerprint the
+// resident-image records are held against (sampled or every byte) and the overlap test that drops them.
+extern "C" int gpc_hip_debug_fingerprint(const uint8_t* smooth, const uint8_t* grad, size_t n, const int32_t* mask, int n_mask,
+                                         int full, uint64_t* fp, const void* a, size_t na, const void* b, size_t nb, int* overlap) {
+  if (!smooth || !grad || !fp || n_mask < 0 || (n_mask > 0 && !mask)) return GPC_E_INVALID;
+  *fp = fingerprint(smooth, grad, n, mask, n_mask, full != 0);
+  if (overlap) *overlap = ranges_overlap(a, na, b, nb) ? 1 : 0;
+  return GPC_OK;
+}
+
 #ifdef GPC_STAMPS
 // diagnostic build only: read and clear the s_memtime phase sums of k_row_join
 extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {

@@ -18,6 +18,9 @@ extern "C" int gpc_hip_debug_expand_pool(const uint32_t* packed, const int32_t* 
                                          const int32_t* counts, int cap, int threads, int parts, gpc_support* out,
                                          const uint8_t* copy_src, uint8_t* copy_dst, size_t copy_bytes);
 
+extern "C" int gpc_hip_debug_fingerprint(const uint8_t* smooth, const uint8_t* grad, size_t n, const int32_t* mask, int n_mask,
+                                         int full, uint64_t* fp, const void* a, size_t na, const void* b, size_t nb, int* overlap);
+
 static uint32_t rng_state = 12345u;
 static uint32_t rnd() {
   rng_state = rng_state * 1664525u + 1013904223u;
@@ -232,9 +235,53 @@ static int cmd_png(const char* dir) {
 }
 #endif
 
+// The fingerprint of a resident image's host copies: arrays of EXACTLY the sizes given (heap blocks: a read past either end
+// is a sanitizer report), sizes from 0 bytes up and not multiples of 8, both modes; one changed byte anywhere changes the
+// full fingerprint, a changed first / last word changes the sampled one; the overlap test on touching and nested ranges.
+static int cmd_fingerprint() {
+  int checked = 0;
+  for (size_t n : {size_t(1), size_t(7), size_t(8), size_t(9), size_t(63), size_t(64), size_t(521), size_t(4099), size_t(70001)}) {
+    for (int n_mask : {0, 1, 2, 3, 17, 1000, 20011}) {
+      std::vector<uint8_t> sm(n), gr(n);
+      std::vector<int32_t> mk((size_t)n_mask);
+      for (auto& v : sm) v = (uint8_t)rnd();
+      for (auto& v : gr) v = (uint8_t)(rnd() & 1 ? 255 : 0);
+      for (auto& v : mk) v = (int32_t)rnd();
+      for (int full = 0; full < 2; ++full) {
+        uint64_t f0 = 0, f1 = 0;
+        if (gpc_hip_debug_fingerprint(sm.data(), gr.data(), n, mk.data(), n_mask, full, &f0, nullptr, 0, nullptr, 0, nullptr)) return 3;
+        if (gpc_hip_debug_fingerprint(sm.data(), gr.data(), n, mk.data(), n_mask, full, &f1, nullptr, 0, nullptr, 0, nullptr) || f0 != f1) return 4;
+        const size_t at = full ? (size_t)(rnd() % n) : (rnd() & 1 ? 0 : n - 1);   // sampled: first and last word are always in
+        sm[at] ^= 0x40;
+        if (gpc_hip_debug_fingerprint(sm.data(), gr.data(), n, mk.data(), n_mask, full, &f1, nullptr, 0, nullptr, 0, nullptr) || f0 == f1) return 5;
+        sm[at] ^= 0x40;
+        if (n_mask) {
+          const size_t am = full ? (size_t)(rnd() % (unsigned)n_mask) : (rnd() & 1 ? 0 : (size_t)n_mask - 1);
+          mk[am] ^= 1;
+          if (gpc_hip_debug_fingerprint(sm.data(), gr.data(), n, mk.data(), n_mask, full, &f1, nullptr, 0, nullptr, 0, nullptr) || f0 == f1) return 6;
+          mk[am] ^= 1;
+        }
+        ++checked;
+      }
+    }
+  }
+  char buf[64];
+  struct { size_t a0, na, b0, nb; int want; } cases[] = {{0, 16, 16, 16, 0}, {0, 17, 16, 16, 1}, {8, 8, 0, 64, 1}, {0, 64, 8, 8, 1},
+                                                         {0, 0, 0, 64, 0}, {32, 8, 0, 32, 0}, {0, 64, 63, 1, 1}};
+  uint64_t f = 0;
+  uint8_t one = 0;
+  for (auto& c : cases) {
+    int ov = -1;
+    if (gpc_hip_debug_fingerprint(&one, &one, 1, nullptr, 0, 0, &f, buf + c.a0, c.na, buf + c.b0, c.nb, &ov) || ov != c.want) return 7;
+  }
+  printf("OK fingerprint %d array sets, sampled and full, overlap cases %zu\n", checked, sizeof cases / sizeof cases[0]);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string cmd = argv[1];
+  if (cmd == "fingerprint") return cmd_fingerprint();
   if (cmd == "forest" && argc == 3) return cmd_forest(argv[2]);
   if (cmd == "expand") return cmd_expand();
   if (cmd == "pool") return cmd_pool();

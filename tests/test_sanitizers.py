@@ -62,6 +62,13 @@ def test_expansion_of_packed_results_under_asan_ubsan(asan_exe):
     assert "OK pool" in run(asan_exe, "pool")
 
 
+def test_resident_image_fingerprint_under_asan_ubsan(asan_exe):
+    """the fingerprint a resident image's host copies are held against (gpc_hip.hip: fingerprint, ranges_overlap): exact-size
+    heap arrays from 1 byte up, sampled and full"""
+    out = run(asan_exe, "fingerprint")
+    assert "OK fingerprint 126 array sets" in out
+
+
 def test_png_decoder_under_asan_ubsan(asan_exe, tmp_path):
     from PIL import Image
     rng = np.random.default_rng(5)
