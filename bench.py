@@ -636,6 +636,32 @@ def main():
                    "unit": "Mpix/s", "identical_outputs_all_pairs": same,
                    "note": "gpc_hip_set_pipeline(ctx, 2): consecutive batches alternate between two lanes of ONE context; "
                            "median of 15 windows of %d steps; not the headline (its kernels overlap, so no clean per-kernel times)" % args.steps}
+            # the same at 32 pairs per step (a rank's share of configs[3] at 8 GPUs): there the join's fill and drain are a
+            # quarter of its launch, which is what the neighbouring batch's kernels fill
+            if B >= 32:
+                for o, n, m in sets:
+                    n.zero_(); m.zero_()
+
+                def step32(i):
+                    o, n, m = sets[i & 1]
+                    c2.match_batch_device(d_L.data_ptr(), d_R.data_ptr(), W, H, 32, settings, o.data_ptr(), cap, n.data_ptr(), m.data_ptr())
+                for i in range(6):
+                    step32(i)
+                c2.synchronize()
+                lane_t = []
+                for _ in range(15):
+                    device_sync(); c2.synchronize()
+                    t2 = time.perf_counter()
+                    for i in range(args.steps):
+                        step32(i)
+                    c2.synchronize()
+                    lane_t.append((time.perf_counter() - t2) / args.steps)
+                dt32 = sorted(lane_t)[len(lane_t) // 2]
+                same32 = bool(all(torch.equal(n[:32], d_counts[:32]) and torch.equal(m[:32], d_ncand[:32]) and
+                                  torch.equal(o[:32], d_out[:32]) and int(n[32:].abs().sum().item()) == 0 for o, n, m in sets))
+                two["share_at_8_gpus"] = {"pairs_per_step": 32, "ms_per_step": round(dt32 * 1e3, 4),
+                                          "value": round(2.0 * W * H * 32 / dt32 / 1e6, 1), "unit": "Mpix/s",
+                                          "identical_outputs_all_pairs": same32}
             c2.close()
             del o2, o3
 
