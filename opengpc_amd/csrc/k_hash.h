@@ -243,9 +243,11 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
         {
           const uint32_t tau_hi = (uint32_t)tau * 0x01000100u;
 #pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            plane[r] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_hi), 0u),
-                                                   plane[r] >> 1, SW_H, 0x4E);
+          for (int r = 0; r < RPW; ++r) {
+            const uint32_t gt = __builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_hi), 0u);
+            // (the first test of a plane: see below)
+            plane[r] = i == 0 ? ~gt : __builtin_amdgcn_bitop3_b32(gt, plane[r] >> 1, SW_H, 0x4E);
+          }
         }
       } else {
 #pragma unroll
@@ -262,7 +264,11 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
           } else {
             ge = swar_ge(av, bv);
           }
-          plane[r] = __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
+          // The first test of a plane takes the compare word as it is (bits 0 .. 6 of its bytes are garbage): whatever lies
+          // below bit 7 after the first step has left the byte after seven more, and the planes with fewer tests are read
+          // through masks that keep only the tests' bits (q0: bit 7 of P8's bytes; q3: the n3 bits m3 selects after the shift
+          // by 8 - n3) -- a shift and a v_bitop3 less per plane and row.
+          plane[r] = i == 0 ? ge : __builtin_amdgcn_bitop3_b32(ge, plane[r] >> 1, SW_H, 0xE4);
         }
       }
     }

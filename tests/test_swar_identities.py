@@ -104,3 +104,31 @@ def test_complemented_plane_forms_of_the_transpose():
         # the shift drags bits of the neighbouring byte in; only the bits m3 selects are code bits -- the others are
         # all-ones in the complemented form (code bit 0) and zero in the plain one
         assert np.array_equal(~plain & M, inv)
+
+
+def test_first_test_of_a_plane_may_carry_garbage_below_bit_7():
+    """k_hash's planes take the first compare word of a plane as it is (bit 7 of each byte = the test, bits 0 .. 6 garbage)
+    instead of inserting it into the plane's initial value.  After n inserts in all (each: plane = (plane >> 1) with bit 7 of
+    every byte replaced) the words read from the planes are the same as with a clean start: the full planes (n = 8) bit for
+    bit, P8 (n = 1) through (p8 >> 7) under m8, the last plane (n = n3 < 8) through the shift by 8 - n3 under m3."""
+    rng = np.random.default_rng(11)
+    M, Hh = np.uint64(0xFFFFFFFF), np.uint64(0x80808080)
+    K = 5000
+    for n in range(1, 9):
+        ge = rng.integers(0, 1 << 32, (n, K), dtype=np.uint64)          # compare words: only bit 7 of each byte means anything
+        clean = np.full(K, 0xFFFFFFFF, np.uint64)                        # the initial value of the planes ("no bit")
+        short = None
+        for i in range(n):
+            clean = ((clean >> np.uint64(1)) & ~Hh & M) | (ge[i] & Hh)
+            short = ge[i] if i == 0 else (((short >> np.uint64(1)) & ~Hh & M) | (ge[i] & Hh))
+        if n == 8:
+            assert np.array_equal(clean, short)
+        if n == 1:
+            for m8 in (np.uint64(0x01010101), np.uint64(0x01010100)):
+                assert np.array_equal((clean >> np.uint64(7)) | (~m8 & M), (short >> np.uint64(7)) | (~m8 & M))
+                assert np.array_equal(((~clean & M) >> np.uint64(7)) & m8, ((~short & M) >> np.uint64(7)) & m8)
+        if n < 8:
+            m3 = np.uint64(0x01010101 * ((1 << n) - 1))
+            s = np.uint64(8 - n)
+            assert np.array_equal((clean >> s) | (~m3 & M), (short >> s) | (~m3 & M))
+            assert np.array_equal(((~clean & M) >> s) & m3, ((~short & M) >> s) & m3)
