@@ -42,8 +42,9 @@ struct GpcForestDev {
   int32_t tau[32];    // (int8_t) tau, sign-extended (SSE arithmetic) / the int as given (Naive arithmetic)
   int32_t num_tests;
   int32_t type;
-  int32_t tau8[8];    // the same taus as bytes, four per word (test t: byte t & 3 of word t >> 2): the SSE kernels read a group's
-                      // eight with ONE 8-byte scalar load instead of eight words (the Tau instantiation spilled SGPRs)
+  int32_t tauk[32];   // SSE arithmetic: the minuend of k_hash's complemented saturating subtract in both 16-bit halves -- 0 for a tau of
+                      // 0 (plain compare), else (tau - 1) * 256 + 255, or tau * 256 in a forest that holds a tau of -128
+  int32_t tau_m128;   // one of these bytes is 0x80 (tau = -128): k_hash takes the complemented subtract that holds for every tau
 };
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }

@@ -2147,7 +2147,7 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
     ft.boff[2 * t] = offt[0] * 4;
     ft.boff[2 * t + 1] = offt[1] * 4;
     f.tau[t] = (int)(int8_t)fm->tau[t];  // _mm_set1_epi8(tau) truncates (filter.hpp:651)
-    f.tau8[t >> 2] |= (int32_t)((uint32_t)(fm->tau[t] & 0xFF) << ((t & 3) * 8));
+    if ((fm->tau[t] & 0xFF) == 0x80) f.tau_m128 = 1;
     // gpcFilterNaive shifts the code left per test: test t ends on bit T-1-t (filter.hpp:245-249)
     const int u = fm->num_tests - 1 - t;
     fn.off[u] = f.off[t];
@@ -2156,7 +2156,11 @@ int gpc_hip_set_forest(gpc_hip_ctx* c, const gpc_filter_mask* fm) {
     fn.tau[u] = fm->tau[t];              // gpcFilterTauNaive uses the int as is (:276)
   }
   memcpy(ft.tau, f.tau, sizeof f.tau);
-  memcpy(ft.tau8, f.tau8, sizeof f.tau8);
+  ft.tau_m128 = f.tau_m128;
+  for (int t = 0; t < fm->num_tests; ++t) {
+    const uint32_t tb = (uint32_t)fm->tau[t] & 0xFFu;
+    f.tauk[t] = ft.tauk[t] = (int32_t)(tb == 0 ? 0u : f.tau_m128 ? tb * 0x01000100u : (((tb - 1u) & 0xFFu) * 0x01000100u) | 0x00FF00FFu);
+  }
   f.num_tests = fn.num_tests = ft.num_tests = fm->num_tests;
   f.type = fn.type = ft.type = fm->type ? 1 : 0;
   c->forest = f;

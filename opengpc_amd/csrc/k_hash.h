@@ -102,19 +102,23 @@ __device__ __forceinline__ uint32_t subs_epi8x4(uint32_t b, uint32_t tau_hi) {
   return __builtin_amdgcn_perm(ro, re, 0x07030501u);  // high bytes back in place: [e.1, o.1, e.3, o.3]
 }
 
-// ~_mm_subs_epi8(b, tau): the bytewise complement of the saturated difference, for EVERY tau.  ~s = -s - 1 maps [-128, 127]
-// onto itself in reverse order, so ~clamp(s - tau) = clamp((tau - 1) - s): the same two packed subtracts with the constant as
-// the minuend.  The byte below the int8 in its 16-bit lane is forced to 255 first (one OR; for the even bytes it rides in
-// the shift: v_lshl_or_b32), the minuend is tau * 256: (tau * 256) - (s * 256 + 255) = (tau - 1 - s) * 256 + 1 leaves
-// [-32768, 32767] exactly when tau - 1 - s leaves [-128, 127], and a saturated lane has the saturated int8 in its high
-// byte.  tau_hi = (tau & 0xFF) << 8 in both halves -- the constant of subs_epi8x4 itself, -128 included (with the low byte
-// left as it lies the minuend would be (tau - 1) * 256 + 255, which -128 does not have in 16 bits: that cost every test
-// of the kernel a three-way branch, ~20 scalar instructions).
-__device__ __forceinline__ uint32_t subs_epi8x4_not(uint32_t b, uint32_t tau_hi) {
-  const uint32_t xe = (b << 8) | 0x00FF00FFu;  // lanes [b0 : 255], [b2 : 255]
-  const uint32_t xo = b | 0x00FF00FFu;         // lanes [b1 : 255], [b3 : 255]
+// ~_mm_subs_epi8(b, tau): the bytewise complement of the saturated difference.  ~s = -s - 1 maps [-128, 127] onto itself in
+// reverse order, so ~clamp(s - tau) = clamp((tau - 1) - s): the same two packed subtracts with the constant as the minuend.
+//   FORCE = false (forests without a tau of -128): the minuend is (tau - 1) * 256 + 255 in both halves and the byte below
+//     the int8 stays as it lies (g): ((tau - 1) * 256 + 255) - (s * 256 + g) = (tau - 1 - s) * 256 + (255 - g) leaves
+//     [-32768, 32767] exactly when tau - 1 - s leaves [-128, 127], and a saturated lane has the saturated int8 in its high
+//     byte: shl, pk_sub, pk_sub, perm.  tau = -128 has no such minuend in 16 bits ((tau - 1) = -129).
+//   FORCE = true (EVERY tau): the byte below the int8 is forced to 255 first (one OR; for the even bytes it rides in the
+//     shift: v_lshl_or_b32) and the minuend is tau * 256: (tau * 256) - (s * 256 + 255) = (tau - 1 - s) * 256 + 1 -- two
+//     operations more per test and row, taken only by forests that hold a tau of -128 (GpcForestDev::tau_m128; deciding it
+//     per test cost every test of the kernel a three-way branch, ~20 scalar instructions).
+// k = the minuend in both 16-bit halves.
+template <bool FORCE>
+__device__ __forceinline__ uint32_t subs_epi8x4_not(uint32_t b, uint32_t k) {
+  const uint32_t xe = FORCE ? ((b << 8) | 0x00FF00FFu) : (b << 8);  // lanes [b0 : 255 / 0], [b2 : 255 / b1]
+  const uint32_t xo = FORCE ? (b | 0x00FF00FFu) : b;                // lanes [b1 : 255 / b0], [b3 : 255 / b2]
   gpc_short2 t, e, o;
-  __builtin_memcpy(&t, &tau_hi, 4);
+  __builtin_memcpy(&t, &k, 4);
   __builtin_memcpy(&e, &xe, 4);
   __builtin_memcpy(&o, &xo, 4);
   e = __builtin_elementwise_sub_sat(t, e);
@@ -180,7 +184,7 @@ __device__ __forceinline__ void fern_test(const uint8_t* __restrict__ tile, int 
 #ifndef HT_PIPE
 #define HT_PIPE 1   // measured per 256 pairs on one box: 0 (compiler's own order) 448 us, 1 -> 439, 2 -> 443, 3 -> 447
 #endif
-template <bool TAU, bool NAIVE, int RPW, int N>
+template <bool TAU, bool NAIVE, int RPW, int N, bool M128 = true>
 __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int lanebase,
                                            const GpcForestDev* __restrict__ fp, int t0, int cnt, uint32_t (&plane)[RPW]) {
 #if HT_PIPE == 0
@@ -192,17 +196,18 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
   uint32_t a[D][RPW], b[D][RPW];
   const uint32_t* base = reinterpret_cast<const uint32_t*>(tile + lanebase);
 #ifndef HT_PACKED_OFFS
-  // the group's tap offsets (and, TAU, the words its tau bytes lie in) in one scalar load ahead of the tests: fetched where
+  // the group's tap offsets (and, TAU, its tests' minuends) in one scalar load ahead of the tests: fetched where
   // each test needs them, the branches a TAU test takes keep the compiler from merging the loads, and every test then
   // waits out a scalar-cache round trip (s_load_dwordx2 + s_waitcnt lgkmcnt(0)) in front of its LDS reads.  boff[] has 64
-  // entries and tau8[] 8 words whatever T is, so slots past `cnt` are readable.
+  // entries and tauk[] 32 whatever T is, so slots past `cnt` are readable.
   uint32_t goff[2 * N];
 #pragma unroll
   for (int i = 0; i < 2 * N; ++i) goff[i] = fp->boff[2 * t0 + i];
-  uint32_t gtau[3] = {0u, 0u, 0u};
+  // (SSE arithmetic: the minuend of each test's complemented subtract, 0 for a tau of 0 -- built by the host, gpc_hip_set_forest)
+  uint32_t gk[N];
   if (TAU && !NAIVE) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gtau[i] = (uint32_t)fp->tau8[min((t0 >> 2) + i, 7)];
+    for (int i = 0; i < N; ++i) gk[i] = (uint32_t)fp->tauk[t0 + i];
   }
 #endif
   auto load = [&](int i, int slot) {
@@ -228,23 +233,23 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
     if (i + HT_PIPE < N && i + HT_PIPE < cnt) load(i + HT_PIPE, (i + HT_PIPE) % D);
     __builtin_amdgcn_sched_barrier(0);
     if (i < cnt) {
-      // SSE arithmetic: the byte of tau (packed four per word); Naive: the int
+      // SSE arithmetic: the test's minuend; Naive: the int
 #ifndef HT_PACKED_OFFS
-      const int tau = !TAU ? 0 : (NAIVE ? fp->tau[t0 + i] : (int)((gtau[((t0 + i) >> 2) - (t0 >> 2)] >> (((t0 + i) & 3) * 8)) & 0xFFu));
+      const uint32_t k = (TAU && !NAIVE) ? gk[i] : 0u;
 #else
-      const int tau = !TAU ? 0 : (NAIVE ? fp->tau[t0 + i] : (int)((((uint32_t)fp->tau8[(t0 + i) >> 2]) >> (((t0 + i) & 3) * 8)) & 0xFFu));
+      const uint32_t k = (TAU && !NAIVE) ? (uint32_t)fp->tauk[t0 + i] : 0u;
 #endif
-      if (TAU && !NAIVE && tau != 0) {
-        // tau is wave-uniform (a scalar load) and the loop is unrolled, so this is a scalar branch per test (a test whose tau
+      const int tau = (TAU && NAIVE) ? fp->tau[t0 + i] : 0;
+      if (TAU && !NAIVE && k != 0u) {
+        // k is wave-uniform (a scalar load) and the loop is unrolled, so this is a scalar branch per test (a test whose tau
         // is 0 -- _mm_subs_epi8(b, 0) = b, 7 of the 30 tests of defaultTauForest.txt -- takes the plain compare below).
         // The compare needs one operand complemented: here the saturating subtract delivers ~b' itself (no v_not),
         // v_lerp_u8(a, ~b', 0) has bit 7 = (a + 255 - b' >= 256) = (a > b') = the code bit, and the plane takes its
         // complement (the planes hold NOT(code bit), complemented once per row at the end).
         {
-          const uint32_t tau_hi = (uint32_t)tau * 0x01000100u;
 #pragma unroll
           for (int r = 0; r < RPW; ++r) {
-            const uint32_t gt = __builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not(b[i % D][r], tau_hi), 0u);
+            const uint32_t gt = __builtin_amdgcn_lerp(a[i % D][r], subs_epi8x4_not<M128>(b[i % D][r], k), 0u);
             // (the first test of a plane: see below)
             plane[r] = i == 0 ? ~gt : __builtin_amdgcn_bitop3_b32(gt, plane[r] >> 1, SW_H, 0x4E);
           }
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   uint32_t cor = 0u;  // OR of the codes computed here (candidates or not: a superset costs the join nothing)
   uint32_t cor3 = 0u; // INV: OR of the last plane's complemented bytes (the codes' bits 24 .. 30), folded into cor at the end
   const int T = fp->num_tests;
+  const bool m128 = TAU && !NAIVE && fp->tau_m128 != 0;  // the forest holds a tau of -128 (wave-uniform, read once)
   int lanebase = (wave * RPW + GPC_R) * HT_STRIDE + 4 * lane + HT_APRON;
   // keep the constant part (13 rows + apron = 3760 bytes) inside the register: left to the compiler it
   // becomes an immediate that no longer fits the 8-bit dword offsets of ds_read2_b32, and every pair of
@@ -533,13 +539,20 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
       if (T > 8) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 8, 8, p1);
       if (T > 16) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 16, 8, p2);
       if (T > 24) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 24, 8, p3);
+    } else if (TAU && m128) {
+      // (a forest with a tau of -128: the complemented subtract that holds for every tau, two operations more per test and row)
+      if (T > 0) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 0, 8, p0);
+      if (T > 8) fern_group<TAU, false, RPW, 1, true>(tile, lanebase, fp, 8, 1, p8);
+      if (T > 9) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 9, 8, p1);
+      if (T > 17) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 17, 8, p2);
+      if (T > 25) fern_group<TAU, false, RPW, 7, true>(tile, lanebase, fp, 25, min(T, 32) - 25, p3);
     } else {
-      if (T > 0) fern_group<TAU, false, RPW, 8>(tile, lanebase, fp, 0, 8, p0);
-      if (T > 8) fern_group<TAU, false, RPW, 1>(tile, lanebase, fp, 8, 1, p8);
-      if (T > 9) fern_group<TAU, false, RPW, 8>(tile, lanebase, fp, 9, 8, p1);
-      if (T > 17) fern_group<TAU, false, RPW, 8>(tile, lanebase, fp, 17, 8, p2);
+      if (T > 0) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 0, 8, p0);
+      if (T > 8) fern_group<TAU, false, RPW, 1, false>(tile, lanebase, fp, 8, 1, p8);
+      if (T > 9) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 9, 8, p1);
+      if (T > 17) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 17, 8, p2);
       // the last plane holds tests 25 .. min(T, 32) - 1: no padded tests here (T = 30: 5, not 7)
-      if (T > 25) fern_group<TAU, false, RPW, 7>(tile, lanebase, fp, 25, min(T, 32) - 25, p3);
+      if (T > 25) fern_group<TAU, false, RPW, 7, false>(tile, lanebase, fp, 25, min(T, 32) - 25, p3);
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {

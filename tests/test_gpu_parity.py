@@ -106,19 +106,30 @@ def test_hash_codes_dense(ctx, oracle, forest_paths, W, H, forest):
             assert np.array_equal(ctx.hash_codes(smooth, g), oracle.hash(smooth, g, f))
 
 
-@pytest.mark.parametrize("taus", ["random", "edges"])
+@pytest.mark.parametrize("taus", ["random", "edges", "random_without_m128", "edges_without_m128", "one_m128"])
 def test_hash_codes_32_tests_full_tau_range(ctx, oracle, taus):
     """32 tests whose tau covers int8: random values, and every value at which the saturating subtract changes regime
-    (-128 has a code path of its own in k_hash, +-127 / +-1 / 0 are its neighbours' limits)."""
+    (+-127 / +-1 / 0 and their neighbours).  A forest that holds a tau of -128 takes k_hash's every-tau form of the
+    complemented subtract (GpcForestDev::tau_m128), every other forest the four-operation form: both, and a forest whose only
+    -128 is its last test."""
     W, H = 160, 100
     rng = np.random.default_rng(5)
     edge = [-128, -127, -126, -1, 0, 1, 2, 126, 127, -128, 64, -64, 127, -127, 1, -1]
+    if taus == "edges_without_m128":
+        edge = [-127, -126, -125, -1, 0, 1, 2, 126, 127, 3, 64, -64, 127, -127, 1, -1]
     lines = ["4"]
     for fern in range(4):
         lines.append("%d l 8" % fern)
         for t in range(8):
             ix, iy, jx, jy = rng.integers(-13, 14, 4)
-            tau = rng.integers(-128, 128) if taus == "random" else edge[(fern * 8 + t) % len(edge)]
+            if taus == "random":
+                tau = rng.integers(-128, 128) if (fern, t) != (1, 3) else -128
+            elif taus in ("random_without_m128", "one_m128"):
+                tau = rng.integers(-127, 128)
+                if taus == "one_m128" and (fern, t) == (3, 7):
+                    tau = 128      # (int8_t) 128 = -128: _mm_set1_epi8 truncates (filter.hpp:651)
+            else:
+                tau = edge[(fern * 8 + t) % len(edge)]
             lines.append("%d %d %d %d %d %d" % (t, ix, iy, jx, jy, tau))
     text = "\n".join(lines)
     import opengpc_amd as g
