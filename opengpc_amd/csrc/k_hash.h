@@ -47,8 +47,10 @@ __device__ unsigned long long g_ht_stamps[16];
     ht_t0 = t_;                                                                             \
   } while (0)
 #define HT_STAMP_FLUSH()                                                                    \
-  if (threadIdx.x == 0 && ((blockIdx.x + blockIdx.y + blockIdx.z) & 31) == 5)               \
-    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ht_stamps[i_], ht_acc[i_])
+  if (threadIdx.x == 0 && ((blockIdx.x + blockIdx.y + blockIdx.z) & 31) == 5) {             \
+    ht_acc[7] = 1; /* slot 7: the number of workgroups that reported */                       \
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ht_stamps[i_], ht_acc[i_]);                   \
+  }
 #define HT_STAMP_INIT()                                                                     \
   unsigned long long ht_t0;                                                                 \
   unsigned long long ht_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                  \

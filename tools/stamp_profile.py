@@ -74,7 +74,7 @@ def main():
     ctx.match_batch(L[:Bh], R[:Bh], hs, cap)
     ctx.L.gpc_hip_debug_htjoin_stamps(ctx.h, buf)
     nwg = Bh * len([b for b in range(210) if (b & 15) == 5])
-    print("k_ht_join phases (s_memtime ticks of thread 0, 10 ns each, per sampled workgroup):")
+    print("k_ht_join phases (s_memtime ticks of thread 0 -- shader clocks on gfx950, ~2.1 per ns -- per sampled workgroup):")
     for i, name in enumerate(HJ):
         print("  %-28s %8.1f ticks" % (name, buf[i] / nwg))
     print("  total %.1f ticks" % (sum(buf[i] for i in range(len(HJ))) / nwg))
