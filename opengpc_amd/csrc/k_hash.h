@@ -47,13 +47,25 @@ __device__ unsigned long long g_ht_stamps[16];
     ht_t0 = t_;                                                                             \
   } while (0)
 #define HT_STAMP_FLUSH()                                                                    \
+  if (threadIdx.x == 0) { /* every workgroup: earliest start, latest start, latest end of the launch (s_memrealtime) */ \
+    unsigned long long rt2_;                                                                  \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt2_)::"memory");         \
+    atomicMax(&g_ht_stamps[8], (1ull << 62) - ht_rt0);                                        \
+    atomicMax(&g_ht_stamps[9], ht_rt0);                                                       \
+    atomicMax(&g_ht_stamps[10], rt2_);                                                        \
+  }                                                                                           \
   if (threadIdx.x == 0 && ((blockIdx.x + blockIdx.y + blockIdx.z) & 31) == 5) {             \
+    unsigned long long rt1_;                                                                  \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");         \
+    ht_acc[6] = rt1_ - ht_rt0; /* slot 6: the workgroup's life in s_memrealtime ticks (100 MHz) */ \
     ht_acc[7] = 1; /* slot 7: the number of workgroups that reported */                       \
     for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ht_stamps[i_], ht_acc[i_]);                   \
   }
 #define HT_STAMP_INIT()                                                                     \
   unsigned long long ht_t0;                                                                 \
   unsigned long long ht_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                  \
+  unsigned long long ht_rt0;                                                                \
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ht_rt0)::"memory");        \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ht_t0)::"memory")
 #else
 #define HT_STAMP(i)

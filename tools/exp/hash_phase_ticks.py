@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Experiment: absolute phase times of k_hash per workgroup (s_memtime ticks = shader clocks on gfx950, ~2.1 per ns: a 13-tile
-workgroup of the 256-pair launch reports 169.5 k ticks for its ~81 us; -DGPC_STAMPS build) for any shape.  Result (round 5): the one-tile
-workgroups of a single 1920x1080 Tau pair run 14.2 k ticks = 6.8 us and of a single 1024x436 pair 9.3 k = 4.4 us, where the launches
-take 29.8 / 13.3 us between HIP events: a one-round launch is launch latency, the end-of-kernel write-back and event overhead, not
-tile time -- nothing for the tile schedule to win there.
+"""Experiment: k_hash's phase times per workgroup (s_memtime ticks = shader clocks on gfx950, ~2.0 per ns), a workgroup's life and
+the launch's extent on the 100 MHz clock (s_memrealtime), for any shape (-DGPC_STAMPS build).  Round 5, what it showed:
+  * one 1920x1080 Tau pair (432 one-tile workgroups on 512 places): every workgroup starts within 0.7 us, a workgroup lives
+    7.4 us on average (10 us where two share a CU), yet the launch takes 29 us between HIP events (21 us with neither tests nor
+    stores, -DHT_EXP_NOCOMPUTE -DHT_EXP_NOSTORE): a one-round launch is launch latency, event overhead, the end-of-kernel
+    write-back and the statistics' atomics -- 216 workgroups per image add to the SAME three words, ~8 ns each in turn (this
+    script's own three atomicMax per workgroup stretch the extent by ~10 us the same way);
+  * one 1024x436 pair (104 workgroups): lives 4.3 us, extent 4.6 us, 13 us between events;
+  * 32 pairs (512 workgroups of 6 / 7 tiles): mean life 40 us, the last ends at 52 us = the launch.
 usage: python tools/exp/hash_phase_ticks.py W H forest pairs"""
 import ctypes as C
 import os
@@ -53,12 +57,24 @@ def main():
     for _ in range(8):
         dev_step()
     ctx.L.gpc_hip_debug_hash_stamps(ctx.h, buf)
+    # launches on their own: the spread of the workgroups' starts and the launch's extent on the 100 MHz clock
+    extent = []
+    for _ in range(5):
+        dev_step()
+        ctx.L.gpc_hip_debug_hash_stamps(ctx.h, buf)
+        first = (1 << 62) - int(buf[8])
+        extent.append(((int(buf[9]) - first) / 100.0, (int(buf[10]) - first) / 100.0))
+    for _ in range(8):
+        dev_step()
+    ctx.L.gpc_hip_debug_hash_stamps(ctx.h, buf)
+    print("per launch: last workgroup start / last workgroup end after the first workgroup's start, us:", extent)
     n = max(int(buf[7]), 1)
     tot = sum(buf[i] for i in range(6))
     print("k_hash, %dx%d %s, %d pair(s): %d workgroup reports; shader-clock ticks per workgroup" % (W, H, forest, B, n))
     for i, name in enumerate(HASH_PHASES):
         print("  %-40s %8.1f ticks  %5.1f %%" % (name, buf[i] / n, 100.0 * buf[i] / max(tot, 1)))
-    print("  %-40s %8.1f ticks ~ %.2f us at 2.1 GHz" % ("total", tot / n, tot / n / 2100.0))
+    print("  %-40s %8.1f ticks; the workgroup's life by s_memrealtime (100 MHz): %.2f us => %.2f s_memtime ticks per ns"
+          % ("total", tot / n, buf[6] / n / 100.0, (tot / n) / max(buf[6] / n * 10.0, 1e-9)))
 
 
 if __name__ == "__main__":
