@@ -3632,6 +3632,13 @@ extern "C" int gpc_hip_debug_htjoin_stamps(gpc_hip_ctx* c, unsigned long long* o
   HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(gpc::g_hj_stamps), zero, sizeof zero));
   return GPC_OK;
 }
+// per workgroup of the last k_hash launches: start, end (s_memrealtime), HW_ID | XCC_ID << 32 (3 words each, 8192 workgroups)
+extern "C" int gpc_hip_debug_hash_workgroups(gpc_hip_ctx* c, unsigned long long* out, int n_wg) {
+  if (!c || !out || n_wg < 1 || n_wg > 8192) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(gpc::g_ht_wg), 3 * sizeof(unsigned long long) * (size_t)n_wg));
+  return GPC_OK;
+}
 extern "C" int gpc_hip_debug_hash_stamps(gpc_hip_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return GPC_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -37,6 +37,7 @@ namespace gpc {
 // summed per phase into a debug buffer nothing else reads.  No stamp executes in the product build.
 #ifdef GPC_STAMPS
 __device__ unsigned long long g_ht_stamps[16];
+__device__ unsigned long long g_ht_wg[3 * 8192];  // per workgroup (flat block id < 8192): start, end (s_memrealtime), hardware id
 #define HT_STAMP(i)                                                                         \
   do {                                                                                      \
     unsigned long long t_;                                                                  \
@@ -53,6 +54,15 @@ __device__ unsigned long long g_ht_stamps[16];
     atomicMax(&g_ht_stamps[8], (1ull << 62) - ht_rt0);                                        \
     atomicMax(&g_ht_stamps[9], ht_rt0);                                                       \
     atomicMax(&g_ht_stamps[10], rt2_);                                                        \
+    const unsigned fb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+    if (fb_ < 8192u) {                                                                        \
+      unsigned hw_, xcc_;                                                                     \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                       \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                     \
+      g_ht_wg[3 * fb_] = ht_rt0;                                                              \
+      g_ht_wg[3 * fb_ + 1] = rt2_;                                                            \
+      g_ht_wg[3 * fb_ + 2] = ((unsigned long long)xcc_ << 32) | hw_;                          \
+    }                                                                                         \
   }                                                                                           \
   if (threadIdx.x == 0 && ((blockIdx.x + blockIdx.y + blockIdx.z) & 31) == 5) {             \
     unsigned long long rt1_;                                                                  \
