@@ -2,13 +2,12 @@
 """Experiment: every workgroup of ONE k_hash launch -- start, end (s_memrealtime, 100 MHz), the XCD / SE / CU it ran on
 (-DGPC_STAMPS build): who are the workgroups a one-round launch waits for?  Round 5:
   * 32 pairs of 1024x436 (512 workgroups of 6 / 7 tiles, two on every CU, all started within 0.5 us): ends 28.9 .. 51.2 us,
-    lives p50 38.6 / p90 49.2 / max 51.0 us.  The older workgroup of a CU gets the issue slots first and ends at 29-39 us, its
-    younger mate at ~50: a CU works its 13 tiles in 50 us = 3.85 us per tile where the 256-pair launch (13-tile workgroups
+    lives p50 38.6 / p90 49.2 / max 51.0 us.  Read as: the older workgroup of a CU gets the issue slots first and ends at
+    29-39 us, its younger mate at ~50: a CU works its 13 tiles in 50 us = 3.85 us per tile where the 256-pair launch (13-tile workgroups
     replaced as they end) runs 3.13 -- the start of a workgroup and its last tiles alone on the CU (8 waves) are what a
     one-round launch pays; every XCD within 2 %.
   * one 1920x1080 Tau pair (432 one-tile workgroups): alone on a CU 7.1 us, two on a CU 9.8 us on average -- and two XCDs of
-    the eight with lives of 18-21 us in that launch (which ones changes from launch to launch): the launch's extent (21 us)
-    is theirs.
+    the eight (1 and 6 in the launch recorded) with lives of 18-21 us: the launch's extent (21 us) is theirs.
 usage: python tools/exp/hash_wg_lives.py W H forest pairs"""
 import ctypes as C
 import os
