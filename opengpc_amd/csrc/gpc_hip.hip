@@ -763,6 +763,9 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
   }
   if (c->hash_tpw > 0) tpw = c->hash_tpw < tiles_y ? c->hash_tpw : tiles_y;  // GPC_HIP_HASH_TPW (tuning)
   dim3 grid(gx, (tiles_y + tpw - 1) / tpw, nimg);
+  // the last `slots` workgroups in dispatch order: the launch's last round (k_hash.h: wave priority by the tiles left)
+  const long nwg_all = (long)grid.x * grid.y * grid.z;
+  const int last_from = nwg_all > slots ? (int)(nwg_all - slots) : 0;
   Timed t(c, KID_HASH);
   const bool tau = c->forest.type != 0;
   int32_t* st = (int32_t*)c->stats.p;
@@ -770,11 +773,11 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
            dense ? "true" : "false", c->naive ? "true" : "false", gbits ? "true" : "false", ty);
 #define LAUNCH_HASH(TAU, DENSE, NAIVE)                                                                    \
   hipLaunchKernelGGL((gpc::k_hash<TAU, DENSE, NAIVE>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + (NAIVE ? 1 : 0), st, tpw)
+                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + (NAIVE ? 1 : 0), st, tpw, last_from)
   if (gbits) {
 #define LAUNCH_HASH_BITS(TAU, TY, FD)                                                                                      \
   hipLaunchKernelGGL((gpc::k_hash<TAU, false, false, true, TY>), grid, dim3(HT_THREADS), 0, c->stream, d_smooth, d_grad, \
-                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + FD, st, tpw)
+                     d_cand, d_codes, W, H, (const GpcForestDev*)c->forest_dev.p + FD, st, tpw, last_from)
     if (ty == HT_Y_TALL) {
       if (tau) LAUNCH_HASH_BITS(true, HT_Y_TALL, 2); else LAUNCH_HASH_BITS(false, HT_Y_TALL, 2);
     } else {

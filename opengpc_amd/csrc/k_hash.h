@@ -337,7 +337,7 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
                                               const uint8_t* __restrict__ candmap,
                                               uint32_t* __restrict__ codes, int W, int H,
                                               const GpcForestDev* __restrict__ fp, int32_t* __restrict__ img_stats,
-                                              int tpw) {
+                                              int tpw, int last_round_from) {
   static_assert(TY % (HT_THREADS / 64) == 0, "a wave owns TY / 8 rows of the tile");
   constexpr int RPW = TY / (HT_THREADS / 64);
   constexpr int T_ROWS = TY + 2 * GPC_R, T_COPY = T_ROWS * HT_STRIDE;  // window rows; bytes of one (shifted) copy of the window
@@ -458,6 +458,11 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   constexpr int CBIT = GBITS ? 0 : 7;   // where cand8 keeps a pixel's candidate flag inside its byte
   const int tile0 = by * tpw;
   const int ntiles = (H - 2 * GPC_R + TY - 1) / TY;
+  // workgroups are dispatched in the order of their flat index: those from `last_round_from` on are the last the places take
+  const bool last_round = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >= last_round_from;
+#ifndef HT_NO_SETPRIO
+  if (!last_round) __builtin_amdgcn_s_setprio(3);
+#endif
   HT_STAMP_INIT();
   fetch(GPC_R + tile0 * TY);
   int cnt = 0, last = -1;
@@ -477,6 +482,24 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
 #pragma unroll 1
   for (int tt = 0; tt < tpw && tile0 + tt < ntiles; ++tt) {
   const int ty0 = GPC_R + (tile0 + tt) * TY;
+#ifndef HT_NO_SETPRIO
+  if (last_round) {
+    // The two workgroups of a CU share its issue slots oldest wave first: the older one runs ahead, ends early, and the
+    // younger works its last tiles alone at half the CU's occupancy (a 32-pair launch: a CU's 13 tiles in 50 us where 41
+    // would do, tools/exp/hash_wg_lives.py).  In the launch's LAST round of workgroups the wave priority follows the tiles a
+    // workgroup has left -- 6 and more: 3, 4-5: 2, 2-3: 1, the last: 0 -- so whoever is behind is served first and both
+    // reach their last tile together: k_hash 51.5 -> 49.0 us at 32 pairs, 89.6 -> 83.5 at 64, 324.5 -> 318.7 at 256
+    // (ladders 3 / 2 / 1 over the last three tiles, by quarters of the workgroup's tiles, 8 / 5 / 3: 0-3 us behind).
+    // Earlier rounds stay at 3 throughout (a place is refilled when a workgroup ends: lowering the priority of ending
+    // workgroups everywhere cost 324 -> 328 us per 256 pairs).
+    const int left = min(tpw - tt, ntiles - tile0 - tt);
+    const int lvl = left >= 6 ? 3 : left >= 4 ? 2 : left >= 2 ? 1 : 0;
+    if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
   if (tt) __syncthreads();  // every wave has finished reading the previous window
   HT_STAMP(0);   // wait for the other waves' tests
   stage();

@@ -87,6 +87,11 @@ def main():
         m = xcc == x
         if m.any():
             print("  XCD %d: %3d workgroups, life mean %.2f  max %.2f, last end %.2f us" % (x, int(m.sum()), life[m].mean(), life[m].max(), end[m].max()))
+    # when the places run dry: how many workgroups are still running t us before the launch's last end
+    for back in (40, 30, 20, 15, 10, 7, 5, 3, 2, 1):
+        t = end.max() - back
+        if t > 0:
+            print("  %5.1f us before the last end: %4d workgroups running, %4d not yet started" % (back, int(((start <= t) & (end > t)).sum()), int((start > t).sum())))
     order = np.argsort(-life)[:12]
     print("longest: " + ", ".join("#%d %.1f us (XCD %d SE %d CU %d)" % (int(np.flatnonzero(used)[i]), life[i], int(xcc[i]), int(se[i]), int(cu[i])) for i in order))
 
