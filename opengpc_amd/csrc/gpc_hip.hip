@@ -3616,6 +3616,15 @@ extern "C" int gpc_hip_debug_fingerprint(const uint8_t* smooth, const uint8_t* g
   return GPC_OK;
 }
 
+#ifdef GPC_WGLIFE
+// diagnostic build only (tools/exp/join_wg_lives.py): per workgroup of the last k_row_join_fused launch start, end, rows | place
+extern "C" int gpc_hip_debug_join_workgroups(gpc_hip_ctx* c, unsigned long long* out, int n_wg) {
+  if (!c || !out || n_wg < 1 || n_wg > 4096) return GPC_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(gpc::g_rjf_wg), 3 * sizeof(unsigned long long) * (size_t)n_wg));
+  return GPC_OK;
+}
+#endif
 #ifdef GPC_STAMPS
 // diagnostic build only: read and clear the s_memtime phase sums of k_row_join
 extern "C" int gpc_hip_debug_stamps(gpc_hip_ctx* c, unsigned long long* out16) {

@@ -325,8 +325,17 @@ constexpr int rjf_log2(int v) {
 // dynamic LDS (RJF_LDS_BYTES): keys [S] | 16-bit flag words [S/2 words] | rank counters [NB] | D: the pending row's
 //       ranked words [NB - 24 >= W - 26]
 #define RJF_LDS_BYTES(NB) ((size_t)6 * pow2_at_least(2 * (NB)) + (size_t)4 * (NB) + (size_t)4 * ((NB) - 24))
+#ifdef GPC_WGLIFE
+// diagnostic build only (tools/exp/join_wg_lives.py): per workgroup start, end (s_memrealtime, 100 MHz), rows | HW_ID | XCC_ID
+__device__ unsigned long long g_rjf_wg[3 * 4096];
+#endif
 template <int SPT, int NT, bool WIDE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_join_fused(RjfArgs ka) {
+#ifdef GPC_WGLIFE
+  unsigned long long wl_t0;
+  unsigned wl_rows = 0u;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wl_t0)::"memory");
+#endif
   static_assert(SPT <= 4 && NT * SPT <= 4096, "16-bit flag words hold 12 bits of x");
   static_assert(NT >= 128, "the second wave draws the tickets");
   constexpr int NB = NT * SPT, S = 1 << rjf_log2(2 * NB);  // (a power of two: 2 * NB but for three slots per thread)
@@ -779,6 +788,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
     RJ_STAMP(6);
     RJ_STAMP_FLUSH();
+#ifdef GPC_WGLIFE
+    ++wl_rows;
+#endif
   }  // rows of this workgroup
 
   {
@@ -805,6 +817,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if (threadIdx.x == 0 && d_t == nrows - 1) rjf_finish_pair(d_pair, base + d_cnt);
     }
   }
+#ifdef GPC_WGLIFE
+  if (threadIdx.x == 0 && blockIdx.x < 4096u) {
+    unsigned long long t1_;
+    unsigned hw_, xcc_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    g_rjf_wg[3 * blockIdx.x] = wl_t0;
+    g_rjf_wg[3 * blockIdx.x + 1] = t1_;
+    g_rjf_wg[3 * blockIdx.x + 2] = ((unsigned long long)wl_rows << 40) | ((unsigned long long)(xcc_ & 0xFu) << 32) | hw_;
+  }
+#endif
 }
 
 }  // namespace gpc
