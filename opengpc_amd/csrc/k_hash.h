@@ -306,6 +306,19 @@ __device__ __forceinline__ void fern_group(const uint8_t* __restrict__ tile, int
 #endif
 }
 
+#ifndef HT_NO_SETPRIO
+#define HT_PRIO_STEP(l) ht_set_prio(min((l), prio_cap))
+#else
+#define HT_PRIO_STEP(l) do { } while (0)
+#endif
+// s_setprio takes an immediate: one scalar branch per level (lvl is wave-uniform)
+__device__ __forceinline__ void ht_set_prio(int lvl) {
+  if (lvl >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+  else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 // bit 7 of every byte of x that is not zero (SWAR)
 __device__ __forceinline__ uint32_t swar_nonzero(uint32_t x) { return (((x & SW_M) + SW_M) | x) & SW_H; }
 
@@ -460,9 +473,6 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   const int ntiles = (H - 2 * GPC_R + TY - 1) / TY;
   // workgroups are dispatched in the order of their flat index: those from `last_round_from` on are the last the places take
   const bool last_round = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >= last_round_from;
-#ifndef HT_NO_SETPRIO
-  if (!last_round) __builtin_amdgcn_s_setprio(3);
-#endif
   HT_STAMP_INIT();
   fetch(GPC_R + tile0 * TY);
   int cnt = 0, last = -1;
@@ -483,22 +493,24 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   for (int tt = 0; tt < tpw && tile0 + tt < ntiles; ++tt) {
   const int ty0 = GPC_R + (tile0 + tt) * TY;
 #ifndef HT_NO_SETPRIO
+  // Wave priorities (s_setprio, 0 .. 3; a CU's arbiter serves the higher one first, then the older wave).
+  //  * Inside a tile the priority steps down with the test groups (3 until test 8, then 2, 1, and 0 from test 25 through the
+  //    stores): a wave that is behind its workgroup is served before one that is ahead, and the eight waves reach the tile's
+  //    barrier together (they waited there for 24 % of the kernel): 318-321 -> 310-315 us per 256 pairs (two levels, 3 then
+  //    0: 315-317; the steps ascending: 321-327).
+  //  * The two workgroups of a CU share its issue slots oldest wave first: the older one runs ahead, ends early, and the
+  //    younger works its last tiles alone at half the CU's occupancy (a 32-pair launch: a CU's 13 tiles in 50 us where 41
+  //    would do, tools/exp/hash_wg_lives.py).  In the launch's LAST round of workgroups the steps are capped by the tiles a
+  //    workgroup has left -- 6 and more: 3, 4-5: 2, 2-3: 1, the last: 0 -- so whoever is behind is served first and both
+  //    reach their last tile together: k_hash 51.5 -> 49.0 us at 32 pairs, 89.6 -> 83.5 at 64, 324.5 -> 318.7 at 256
+  //    (caps 3 / 2 / 1 over the last three tiles, by quarters of the workgroup's tiles, 8 / 5 / 3: 0-3 us behind; a cap
+  //    in every round, where a place is refilled when a workgroup ends, cost 324 -> 328 us per 256 pairs).
+  int prio_cap = 3;
   if (last_round) {
-    // The two workgroups of a CU share its issue slots oldest wave first: the older one runs ahead, ends early, and the
-    // younger works its last tiles alone at half the CU's occupancy (a 32-pair launch: a CU's 13 tiles in 50 us where 41
-    // would do, tools/exp/hash_wg_lives.py).  In the launch's LAST round of workgroups the wave priority follows the tiles a
-    // workgroup has left -- 6 and more: 3, 4-5: 2, 2-3: 1, the last: 0 -- so whoever is behind is served first and both
-    // reach their last tile together: k_hash 51.5 -> 49.0 us at 32 pairs, 89.6 -> 83.5 at 64, 324.5 -> 318.7 at 256
-    // (ladders 3 / 2 / 1 over the last three tiles, by quarters of the workgroup's tiles, 8 / 5 / 3: 0-3 us behind).
-    // Earlier rounds stay at 3 throughout (a place is refilled when a workgroup ends: lowering the priority of ending
-    // workgroups everywhere cost 324 -> 328 us per 256 pairs).
     const int left = min(tpw - tt, ntiles - tile0 - tt);
-    const int lvl = left >= 6 ? 3 : left >= 4 ? 2 : left >= 2 ? 1 : 0;
-    if (lvl == 3) __builtin_amdgcn_s_setprio(3);
-    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
+    prio_cap = left >= 6 ? 3 : left >= 4 ? 2 : left >= 2 ? 1 : 0;
   }
+  ht_set_prio(prio_cap);
 #endif
   if (tt) __syncthreads();  // every wave has finished reading the previous window
   HT_STAMP(0);   // wait for the other waves' tests
@@ -583,21 +595,30 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
     if (NAIVE) {
       // slot u -> bit u: four full byte planes, no special test 8 (slots >= T are padded with equal taps)
       if (T > 0) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 0, 8, p0);
+      HT_PRIO_STEP(2);
       if (T > 8) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 8, 8, p1);
+      HT_PRIO_STEP(1);
       if (T > 16) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 16, 8, p2);
+      HT_PRIO_STEP(0);
       if (T > 24) fern_group<TAU, true, RPW, 8>(tile, lanebase, fp, 24, 8, p3);
     } else if (TAU && m128) {
       // (a forest with a tau of -128: the complemented subtract that holds for every tau, two operations more per test and row)
       if (T > 0) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 0, 8, p0);
       if (T > 8) fern_group<TAU, false, RPW, 1, true>(tile, lanebase, fp, 8, 1, p8);
+      HT_PRIO_STEP(2);
       if (T > 9) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 9, 8, p1);
+      HT_PRIO_STEP(1);
       if (T > 17) fern_group<TAU, false, RPW, 8, true>(tile, lanebase, fp, 17, 8, p2);
+      HT_PRIO_STEP(0);
       if (T > 25) fern_group<TAU, false, RPW, 7, true>(tile, lanebase, fp, 25, min(T, 32) - 25, p3);
     } else {
       if (T > 0) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 0, 8, p0);
       if (T > 8) fern_group<TAU, false, RPW, 1, false>(tile, lanebase, fp, 8, 1, p8);
+      HT_PRIO_STEP(2);
       if (T > 9) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 9, 8, p1);
+      HT_PRIO_STEP(1);
       if (T > 17) fern_group<TAU, false, RPW, 8, false>(tile, lanebase, fp, 17, 8, p2);
+      HT_PRIO_STEP(0);
       // the last plane holds tests 25 .. min(T, 32) - 1: no padded tests here (T = 30: 5, not 7)
       if (T > 25) fern_group<TAU, false, RPW, 7, false>(tile, lanebase, fp, 25, min(T, 32) - 25, p3);
     }
