@@ -325,6 +325,21 @@ constexpr int rjf_log2(int v) {
 // dynamic LDS (RJF_LDS_BYTES): keys [S] | 16-bit flag words [S/2 words] | rank counters [NB] | D: the pending row's
 //       ranked words [NB - 24 >= W - 26]
 #define RJF_LDS_BYTES(NB) ((size_t)6 * pow2_at_least(2 * (NB)) + (size_t)4 * (NB) + (size_t)4 * ((NB) - 24))
+// Wave priority by the phase of the row (s_setprio at the phase boundaries; a CU's arbiter serves the higher priority first,
+// then the older wave).  Left alone, the eight workgroups of a CU are served oldest first whatever they are doing; with
+// the priority RISING through the row -- 0 while the codes arrive, 1 for the insert, 2 for the lookups, 3 from the decide
+// phase to the end -- a row that is further along is finished first: 522 -> 502 us per 256 pairs, 89.5 -> 85.1 at 32
+// (tools/exp/ab_join_prio.sh; seven hex digits, phase 0 leftmost: 0012233 / 0012333 506, 0011223 506, 0112233 509,
+// 0133333 / 0233333 / 1233333 505, 0123222 / 0123210 505 (83.9 at 32 pairs), 0001233 513, 0000333 517, 0333333 513; falling:
+// 3321100 511 (83.6 at 32 pairs), 3333210 514).
+#ifndef RJF_PRIO_PAT
+#define RJF_PRIO_PAT 0x0123333
+#endif
+#ifndef RJF_NO_PRIO
+#define RJF_PRIO(ph) __builtin_amdgcn_s_setprio((RJF_PRIO_PAT >> (4 * (6 - (ph)))) & 3)
+#else
+#define RJF_PRIO(ph) do { } while (0)
+#endif
 #ifdef GPC_WGLIFE
 // diagnostic build only (tools/exp/join_wg_lives.py): per workgroup start, end (s_memrealtime, 100 MHz), rows | HW_ID | XCC_ID
 __device__ unsigned long long g_rjf_wg[3 * 4096];
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     }
     RJ_STAMP_INIT();
+    RJF_PRIO(0);
     // ---- 0. this row's keys; key table and rank counters cleared (16-byte stores)
     uint32_t kl[SPT], kr[SPT];  // stored key = code + 1 (0 = no record in this pixel slot)
 #pragma unroll
@@ -501,6 +517,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();  // B0: table and counters clear; the previous row's walk is over everywhere (its codes lie in the flag words)
     RJ_STAMP(0);
+    RJF_PRIO(1);
 
     // ---- 1. build the ordered table from the left codes; the flag words are cleared meanwhile (the inserts touch keys only)
     uint32_t h0l[SPT];
@@ -566,6 +583,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();  // B1
     RJ_STAMP(1);
+    RJF_PRIO(2);
     // The first wave asks for the granules of the PENDING row's predecessors here and looks at the answer after the
     // lookup phase (the wave has no other vector-memory operation in flight then: its counter is in order, and a wait
     // for an older load would wait for this one too).  Who does what is spread over the waves for the same reason: the
@@ -663,6 +681,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();  // B2
     RJ_STAMP(2);
+    RJF_PRIO(3);
     if (d_t >= 0 && tid < 64) {  // the pending row's place: supports of the pair's rows before it
       RjfK* a = rjf_args();
       unsigned long long* d_st = a->status + (long)d_pair * (ka.H - 2 * GPC_R) + d_t;
@@ -736,6 +755,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (tid == 64) s_ticket = f_nxt;  // (waits for the draw made at the top of the insert phase)
     __syncthreads();  // B3: every match is counted; the flag words are dead from here on (their LDS takes the codes of shared buckets)
     RJ_STAMP(3);
+    RJF_PRIO(4);
     // this row's count goes out at once (later rows of the pair may be waiting for it)
     const uint32_t f_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt);
     if (tid == 0) {
@@ -758,6 +778,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if (tid == 0 && d_t == ka.H - 2 * GPC_R - 1) rjf_finish_pair(d_pair, base + d_cnt);  // the pair's last row
     }
     RJ_STAMP(4);
+    RJF_PRIO(5);
     block_exscan<SPT, NT, false>(r_cnt, s_w, tid);  // r_cnt[b] = first rank of bucket b     (B4, B5)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
@@ -767,6 +788,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     __syncthreads();  // B6
     RJ_STAMP(5);
+    RJF_PRIO(6);
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const bool m = ok[j];
