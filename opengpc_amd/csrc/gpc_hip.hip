@@ -744,7 +744,9 @@ int run_hash(gpc_hip_ctx* c, const uint8_t* d_smooth, const uint8_t* d_grad, con
     for (int t = 2; t <= 16 && t <= tiles_y; ++t) {
       const long per_col = (tiles_y + t - 1) / t, ncol = (long)gx * nimg;
       const long nwg = per_col * ncol;
-      if (nwg < slots) break;
+      // (a split that leaves a few places empty still counts: one 3840x2160 pair is 15 x 67 x 2 tiles = 510 workgroups of 4 for
+      //  512 places -- 57 us where 1020 workgroups of 2 take 60, and 68 with k_hash's wave priorities)
+      if (nwg * 8 < (long)slots * 7) break;
       const int rem = tiles_y - (int)(per_col - 1) * t;             // tiles of a column's last workgroup (1 .. t)
       const long n_full = (per_col - 1) * ncol, n_rem = ncol;         // workgroups of t tiles / of rem tiles
       // full-size workgroups dealt over the places first, the short ones onto the least loaded places

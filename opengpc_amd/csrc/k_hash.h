@@ -503,8 +503,9 @@ __global__ __launch_bounds__(HT_THREADS) HT_OCC void k_hash(const uint8_t* __res
   //    would do, tools/exp/hash_wg_lives.py).  In the launch's LAST round of workgroups the steps are capped by the tiles a
   //    workgroup has left -- 6 and more: 3, 4-5: 2, 2-3: 1, the last: 0 -- so whoever is behind is served first and both
   //    reach their last tile together: k_hash 51.5 -> 49.0 us at 32 pairs, 89.6 -> 83.5 at 64, 324.5 -> 318.7 at 256
-  //    (caps 3 / 2 / 1 over the last three tiles, by quarters of the workgroup's tiles, 8 / 5 / 3: 0-3 us behind; a cap
-  //    in every round, where a place is refilled when a workgroup ends, cost 324 -> 328 us per 256 pairs).
+  //    (caps 3 / 2 / 1 over the last three tiles, by quarters of the workgroup's tiles, 8 / 5 / 3: 0-3 us behind, and
+  //    within 1 % of each other over the BASELINE configurations, tools/exp/ab_configs.sh; a cap in every round, where a
+  //    place is refilled when a workgroup ends, cost 324 -> 328 us per 256 pairs).
   int prio_cap = 3;
   if (last_round) {
     const int left = min(tpw - tt, ntiles - tile0 - tt);

@@ -34,7 +34,10 @@ CONFIGS = [
 def main():
     dev = torch.device("cuda", 0)
     out = []
+    only = os.environ.get("GPC_CONFIGS")   # substring filter (GPC_CONFIGS="C5 single"): the other configurations are skipped
     for name, W, H, forest, s, D, B, epi, ht in CONFIGS:
+        if only and only not in name:
+            continue
         ctx = g.Context(0)
         stream = torch.cuda.Stream(device=dev)
         ctx.set_stream(stream.cuda_stream)
