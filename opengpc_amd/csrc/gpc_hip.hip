@@ -946,14 +946,14 @@ int run_match(gpc_hip_ctx* c, int W, int H, int npairs, const gpc_settings* s, i
                 !(po && po->totals) && (long)npairs * (H - 2 * GPC_R) < (1l << 31) - 65536;
     if (fuse && !c->fuse_always) {
       // The persistent launch pays off once every workgroup takes several rows (its output lags one row behind, and the
-      // last row of a workgroup is placed with a blocking look-back): measured against join + k_gather_rows,
-      // 1024x436: 1 .. 24 pairs 3-10 % slower, 32 pairs even, 48 .. 256 pairs 4-11 % faster; 1920x1080: one pair 6 % slower,
-      // 8 pairs 8 % faster; one 3840x2160 pair 9 % faster.  Rows per resident workgroup >= 6, or >= 3 for rows of
-      // 2048 px and more, is where it wins.
+      // last row of a workgroup is placed with a blocking look-back): measured against join + k_gather_rows (round 5, with
+      // the wave priorities of k_rowjoin_fused.h), 1024x436 steps: 4 .. 16 pairs 4-14 % slower, 20 / 24 pairs 3 % faster,
+      // 28 pairs 8 %, 32 .. 256 pairs 8-11 %; 1920x1080: one pair 6 % slower, 8 pairs 8 % faster; one 3840x2160 pair 9 %
+      // faster.  Rows per resident workgroup >= 4, or >= 3 for rows of 2048 px and more, is where it wins.
       const long lds_wgs = (long)(160 * 1024 / (flds + 64)), wave_wgs = 32 / (jp.nt / 64);
       const long resident = (long)c->num_cus * (lds_wgs < wave_wgs ? lds_wgs : wave_wgs);
       const long rows_total = (long)npairs * (H - 2 * GPC_R);
-      fuse = rows_total >= 6 * resident || (W >= 2048 && rows_total >= 3 * resident);
+      fuse = rows_total >= 4 * resident || (W >= 2048 && rows_total >= 3 * resident);
     }
     if (fuse) {
       // k_row_join_fused (k_rowjoin_fused.h): one by-value parameter the kernel reads from its argument segment
